@@ -1,0 +1,397 @@
+// Attention kernels for gfx950.
+//
+// (1) attn_d64_kernel -- flash-style forward for head_dim 64 (the spatial
+//     self-attention of BasicTransformerBlock, sgm/modules/attention.py:332-336 /
+//     427-439; S up to 16384 tokens).  One block = 128 query rows of one (batch, head),
+//     4 waves x 32 rows.  K and V^T tiles of 64 keys are LDS-DMA'd (global_load_lds)
+//     into a 2-stage ring with a source-side XOR swizzle (conflict-free ds_read_b128).
+//     Both matrix products run on v_mfma_f32_32x32x16_bf16 in "swapped" form,
+//         S^T[kv][q] = K . Q^T         O^T[d][q] = V^T . P^T
+//     so that every lane owns ONE query row: softmax statistics, the running-max
+//     rescale and the final 1/l are lane-local, and P (C-layout of the first product)
+//     is already the B-operand layout of the second -- no LDS round trip, no cross-lane
+//     permutes.  The key rows of each 32-key block are fed to the MFMA with bits 2 and
+//     3 of the row index swapped, which makes the accumulator registers of a lane hold
+//     8 *consecutive* keys per group -- exactly one 16-byte V^T fragment.
+//
+// (2) transpose_v_kernel -- V[(b,s), h*64+d] -> V^T[b][h][d][s] (zero padded to 64).
+//
+// (3) attn_temporal_kernel -- softmax attention over the frame axis (T <= 32) at every
+//     pixel (sgm/modules/video_attention.py:114-125), reading the frame-major token
+//     layout directly; VALU kernel on v_dot2c_f32_bf16 (0.05 % of the step FLOPs, its
+//     cost is the q/k/v/o traffic).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swap_bits23(int i) {
+  return (i & ~0xC) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+
+struct AttnParams {
+  const char* q; const char* k; const char* vt; unsigned short* out;
+  int B, H, Sq, Skv, ldq, ldk, ldvt, ldo, nqt;
+  float scale_log2;   // softmax scale * log2(e)
+};
+
+constexpr int KV_TILE = 64;
+constexpr int ATT_STAGE = 2 * KV_TILE * 128;   // K tile 8 KiB + V^T tile 8 KiB
+
+__global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+
+  // XCD-aware mapping: the query tiles of one (b, h) are consecutive logical ids and
+  // stay on one XCD, so its K / V^T stream is fetched into a single L2.
+  const int nblk = gridDim.x;
+  int lid;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qt = lid % p.nqt, bh = lid / p.nqt;
+  const int h = bh % p.H, b = bh / p.H;
+
+  const char* zero = (const char*)hi3d_zero_page;
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[row li][d = ks*16 + hi*8 ..+7]
+  const int qrow = qt * 128 + w * 32 + li;
+  const bool qok = qrow < p.Sq;
+  bf16x8 qf[4];
+  {
+    const char* qp = p.q + (((long)b * p.Sq + (qok ? qrow : 0)) * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = qok ? *(const bf16x8*)(qp + (ks * 16 + hi * 8) * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
+  // ---- LDS-DMA gather state: K tile rows (keys) and V^T tile rows (d), 8 KiB each =
+  // 8 pieces of 1 KiB; wave w moves pieces 2w, 2w+1 of both.
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const char* kbase = p.k + ((long)b * p.Skv * p.ldk + h * 64) * 2;
+  const char* vbase = p.vt + ((long)(b * p.H + h) * 64) * (long)p.ldvt * 2;
+  int k_r[2], k_c[2], v_c[2]; long v_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (w * 2 + i) * 8 + lrow;               // LDS row 0..63
+    k_r[i] = r;
+    k_c[i] = lslot ^ ((swap_bits23(r & 31) >> 1) & 7);   // read by MFMA row swap(r)
+    v_c[i] = lslot ^ ((r >> 1) & 7);
+    v_off[i] = (long)r * p.ldvt * 2;
+  }
+  auto issue = [&](int j, int st) {
+    char* sK = smem + st * ATT_STAGE;
+    char* sV = sK + KV_TILE * 128;
+    const int kv0 = j * KV_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kv = kv0 + k_r[i];
+      const char* src = kbase + ((long)kv * p.ldk + k_c[i] * 8) * 2;
+      lds_dma16(kv < p.Skv ? src : zero, sK + (w * 2 + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* src = vbase + v_off[i] + (long)(kv0 + v_c[i] * 8) * 2;   // padded to 64: always in range
+      lds_dma16(src, sV + (w * 2 + i) * 1024);
+    }
+  };
+
+  // fragment read offsets
+  const int k_sw = (li >> 1) & 7, v_sw = (li >> 1) & 7;
+  int k_off[2], vt_off[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) k_off[kb] = (kb * 32 + swap_bits23(li)) * 128;
+#pragma unroll
+  for (int db = 0; db < 2; ++db) vt_off[db] = KV_TILE * 128 + (db * 32 + li) * 128;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntile = (p.Skv + KV_TILE - 1) / KV_TILE;
+  issue(0, 0);
+  for (int j = 0; j < ntile; ++j) {
+    const int st = j & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j + 1 < ntile) issue(j + 1, st ^ 1);
+    const char* s = smem + st * ATT_STAGE;
+
+    // S^T = K Q^T  (two 32-key blocks)
+    f32x16 sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(s + k_off[kb] + (((ks * 2 + hi) ^ k_sw) << 4));
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+      }
+    }
+    // lane registers: sc[kb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
+    if ((j + 1) * KV_TILE > p.Skv) {   // ragged last tile: mask keys >= Skv
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
+          if (kv >= p.Skv) sc[kb][r] = -INFINITY;
+        }
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);   // finite: every tile has >= 1 valid key
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float e[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          e[t] = exp2f(sc[kb][half * 8 + t] * p.scale_log2 - m_new);
+          psum += e[t];
+        }
+        union { bf16x8 v; unsigned int u[4]; } pk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pk.u[t] = pack_bf16x2(e[2 * t], e[2 * t + 1]);
+        pf[kb * 2 + half] = pk.v;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+    // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 vf = *(const bf16x8*)(s + vt_off[db] + (((ks * 2 + hi) ^ v_sw) << 4));
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
+      }
+  }
+
+  // ---- finish: both half-waves hold partial row sums of the same query row
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qok) {
+    unsigned short* op = p.out + ((long)b * p.Sq + qrow) * p.ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // C rows (r&3) + 8*(r>>2) + 4*hi  ->  d = db*32 + g*8 + hi*4 + (0..3)
+        uint2 v;
+        v.x = pack_bf16x2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+        v.y = pack_bf16x2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+        *(uint2*)(op + db * 32 + g * 8 + hi * 4) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_v_kernel(const unsigned short* __restrict__ v,
+                                                          unsigned short* __restrict__ vt,
+                                                          int H, int S, int S_pad, int ldv) {
+  __shared__ unsigned short tile[64][66];   // [s][d], +2 pad
+  const int st = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int s0 = st * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;            // 512 chunks of 8 bf16
+    const int sr = c >> 3, dc = (c & 7) * 8;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (s0 + sr < S) q = *(const uint4*)(v + ((long)b * S + s0 + sr) * ldv + h * 64 + dc);
+    const unsigned int u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tile[sr][dc + 2 * j] = (unsigned short)(u[j] & 0xffff);
+      tile[sr][dc + 2 * j + 1] = (unsigned short)(u[j] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;
+    const int d = c >> 3, sc = (c & 7) * 8;
+    unsigned int u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      u[j] = (unsigned int)tile[sc + 2 * j][d] | ((unsigned int)tile[sc + 2 * j + 1][d] << 16);
+    *(uint4*)(vt + (((long)b * H + h) * 64 + d) * S_pad + s0 + sc) = make_uint4(u[0], u[1], u[2], u[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
+__device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, a), __builtin_bit_cast(v2bf, b), c, false);
+}
+
+// block = PB pixels x TP frames (PB*TP = 256) of one (batch, head); thread = (pixel, query frame)
+template <int TP>
+__global__ __launch_bounds__(256) void attn_temporal_kernel(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+    const unsigned short* __restrict__ v, unsigned short* __restrict__ out,
+    int T, int S, int ld, int ldo, float scale_log2) {
+  constexpr int PB = 256 / TP;
+  constexpr int KPIX = TP * 128 + 16;            // bytes of keys per pixel (+16: spreads pixels over banks)
+  constexpr int VROW = TP * 2;                   // bytes per (pixel, d) row of V^T
+  constexpr int VPIX = 64 * VROW + 16;
+  __shared__ __attribute__((aligned(16))) char sK[PB * KPIX];
+  __shared__ __attribute__((aligned(16))) char sV[PB * VPIX];
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * PB, h = blockIdx.y, b = blockIdx.z;
+
+  // ---- stage K rows and transposed V: 8 chunks of 16 B per (pixel, frame)
+  for (int c = tid; c < PB * TP * 8; c += 256) {
+    const int ch = c & 7, row = c >> 3;
+    const int t = row % TP, px = row / TP;
+    uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+    if (t < T && s0 + px < S) {
+      const long off = (((long)b * T + t) * S + s0 + px) * ld + h * 64 + ch * 8;
+      kq = *(const uint4*)(k + off);
+      vq = *(const uint4*)(v + off);
+    }
+    *(uint4*)(sK + px * KPIX + t * 128 + ch * 16) = kq;
+    const unsigned int u[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(unsigned short*)(sV + px * VPIX + (ch * 8 + 2 * j) * VROW + t * 2) = (unsigned short)(u[j] & 0xffff);
+      *(unsigned short*)(sV + px * VPIX + (ch * 8 + 2 * j + 1) * VROW + t * 2) = (unsigned short)(u[j] >> 16);
+    }
+  }
+  __syncthreads();
+
+  const int tq = tid % TP, px = tid / TP;
+  if (tq >= T || s0 + px >= S) return;
+  const long qoff = (((long)b * T + tq) * S + s0 + px) * ld + h * 64;
+  unsigned int qr[32];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint4 t4 = *(const uint4*)(q + qoff + c * 8);
+    qr[c * 4] = t4.x; qr[c * 4 + 1] = t4.y; qr[c * 4 + 2] = t4.z; qr[c * 4 + 3] = t4.w;
+  }
+  float sc[TP];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+    const char* kr = sK + px * KPIX + t * 128;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint4 k4 = *(const uint4*)(kr + c * 16);
+      a0 = dot2_bf16(qr[c * 4], k4.x, a0); a1 = dot2_bf16(qr[c * 4 + 1], k4.y, a1);
+      a0 = dot2_bf16(qr[c * 4 + 2], k4.z, a0); a1 = dot2_bf16(qr[c * 4 + 3], k4.w, a1);
+    }
+    sc[t] = (t < T) ? (a0 + a1) * scale_log2 : -INFINITY;
+    mx = fmaxf(mx, sc[t]);
+  }
+  float l = 0.f;
+  unsigned int pp[TP / 2];
+#pragma unroll
+  for (int t = 0; t < TP; t += 2) {
+    const float e0 = exp2f(sc[t] - mx), e1 = exp2f(sc[t + 1] - mx);
+    l += e0 + e1;
+    pp[t / 2] = pack_bf16x2(e0, e1);
+  }
+  const float inv = 1.0f / l;
+  unsigned short* op = out + (((long)b * T + tq) * S + s0 + px) * ldo + h * 64;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float od[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* vr = sV + px * VPIX + (c * 8 + j) * VROW;
+      float a = 0.f;
+#pragma unroll
+      for (int t4 = 0; t4 < TP / 8; ++t4) {
+        const uint4 vv = *(const uint4*)(vr + t4 * 16);
+        a = dot2_bf16(pp[t4 * 4], vv.x, a); a = dot2_bf16(pp[t4 * 4 + 1], vv.y, a);
+        a = dot2_bf16(pp[t4 * 4 + 2], vv.z, a); a = dot2_bf16(pp[t4 * 4 + 3], vv.w, a);
+      }
+      od[j] = a * inv;
+    }
+    *(uint4*)(op + c * 8) = make_uint4(pack_bf16x2(od[0], od[1]), pack_bf16x2(od[2], od[3]),
+                                       pack_bf16x2(od[4], od[5]), pack_bf16x2(od[6], od[7]));
+  }
+}
+
+}  // namespace
+
+extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
+                             int32_t B, int32_t H, int32_t S_q, int32_t S_kv, int32_t ldq,
+                             int32_t ldk, int32_t ld_vt, int32_t ldo, float scale, void* stream) {
+  if (!q || !k || !vt || !out) HI3D_FAIL(HI3D_EINVAL, "attn_d64: null pointer");
+  if (B <= 0 || H <= 0 || S_q <= 0 || S_kv <= 0) HI3D_FAIL(HI3D_EINVAL, "attn_d64: non-positive size");
+  if (ldq < H * 64 || ldk < H * 64 || ldo < H * 64) HI3D_FAIL(HI3D_EINVAL, "attn_d64: leading dim < H*64");
+  if ((ldq % 8) || (ldk % 8) || (ldo % 4)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: leading dims must keep 16-byte rows");
+  if (ld_vt % 64 || ld_vt < S_kv) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: ld_vt must be S_kv rounded up to 64");
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: misaligned pointer");
+  AttnParams p;
+  p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)vt; p.out = (unsigned short*)out;
+  p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_vt; p.ldo = ldo;
+  p.nqt = (S_q + 127) / 128;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  const long nblk = (long)p.nqt * H * B;
+  if (nblk > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: grid too large");
+  hipLaunchKernelGGL(attn_d64_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
+                                int32_t S_pad, int32_t ldv, void* stream) {
+  if (!v || !vt) HI3D_FAIL(HI3D_EINVAL, "transpose_v: null pointer");
+  if (B <= 0 || H <= 0 || S <= 0) HI3D_FAIL(HI3D_EINVAL, "transpose_v: non-positive size");
+  if (S_pad % 64 || S_pad < S || S_pad - S >= 64) HI3D_FAIL(HI3D_ESHAPE, "transpose_v: S_pad must be S rounded up to 64");
+  if (ldv % 8 || ldv < H * 64) HI3D_FAIL(HI3D_EALIGN, "transpose_v: bad ldv");
+  if (((uintptr_t)v | (uintptr_t)vt) & 15) HI3D_FAIL(HI3D_EALIGN, "transpose_v: misaligned pointer");
+  if (H > 65535 || B > 65535) HI3D_FAIL(HI3D_ESHAPE, "transpose_v: grid too large");
+  hipLaunchKernelGGL(transpose_v_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)v, (unsigned short*)vt, H, S, S_pad, ldv);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_attn_temporal_d64(const void* q, const void* k, const void* v, void* out,
+                                      int32_t B, int32_t T, int32_t S, int32_t H, int32_t ldqkv,
+                                      int32_t ldo, float scale, void* stream) {
+  if (!q || !k || !v || !out) HI3D_FAIL(HI3D_EINVAL, "attn_temporal: null pointer");
+  if (B <= 0 || T <= 0 || S <= 0 || H <= 0) HI3D_FAIL(HI3D_EINVAL, "attn_temporal: non-positive size");
+  if (T > 32) HI3D_FAIL(HI3D_ESHAPE, "attn_temporal: T > 32 not supported");
+  if (ldqkv % 8 || ldo % 8 || ldqkv < H * 64 || ldo < H * 64) HI3D_FAIL(HI3D_EALIGN, "attn_temporal: bad leading dim");
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) HI3D_FAIL(HI3D_EALIGN, "attn_temporal: misaligned pointer");
+  if (H > 65535 || B > 65535) HI3D_FAIL(HI3D_ESHAPE, "attn_temporal: grid too large");
+  const float sl2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  if (T <= 8) {
+    constexpr int TP = 8, PB = 256 / TP;
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+  } else if (T <= 16) {
+    constexpr int TP = 16, PB = 256 / TP;
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+  } else {
+    constexpr int TP = 32, PB = 256 / TP;
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+  }
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}

@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 kernels of libhi3d_hip.so.
+// Written for CDNA4 only: 64-wide wavefronts, bf16 MFMA, LDS-DMA (global_load_lds).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hi3d_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// 256 B of zeros in device memory: out-of-range gather lanes of an LDS-DMA read
+// this instead of branching (global_load_lds has no predicated-zero form).
+static __device__ uint4 hi3d_zero_page[16];  // zero-initialised, one copy per TU
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) {
+  return __uint_as_float(((unsigned int)u) << 16);
+}
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+// 16-byte LDS-DMA: each lane supplies its own global source, the LDS destination
+// is the wave-uniform `lds_wave_base` + lane*16 (hardware adds the lane part).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host side ---------------------------------------------------------------
+void hi3d_set_error(const char* msg);
+#define HI3D_FAIL(code, msg) do { hi3d_set_error(msg); return (code); } while (0)
+#define HI3D_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e_ = hipGetLastError();                        \
+    if (e_ != hipSuccess) {                                   \
+      hi3d_set_error(hipGetErrorString(e_));                  \
+      return (int)e_;                                         \
+    }                                                         \
+  } while (0)

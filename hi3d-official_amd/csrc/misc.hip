@@ -1,0 +1,186 @@
+// Small layout / elementwise kernels of the sampler step (gfx950).  All are
+// bandwidth-trivial next to the UNet; what matters is that each replaces a chain of
+// tiny launches in the reference (guiders.py:88-99, denoiser.py:36-39, wrappers.py:26,
+// sampling.py:93-107) with a single pass.
+#include "common.h"
+
+namespace {
+
+__global__ void concat_channels_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                       uint4* __restrict__ out, long rows, int v0, int v1) {
+  const int vt = v0 + v1;
+  const long total = rows * vt;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / vt; const int c = (int)(i - r * vt);
+    out[i] = c < v0 ? a[r * v0 + c] : b[r * v1 + (c - v0)];
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, void* __restrict__ out, int n, int dim,
+                                          float neg_log_period_over_half, int out_bf16) {
+  const int half = dim / 2;
+  const int i = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+  if (i >= n || j >= dim) return;
+  float val = 0.f;
+  if (j < 2 * half) {
+    const int jj = j < half ? j : j - half;
+    const float arg = t[i] * expf(neg_log_period_over_half * (float)jj);
+    val = j < half ? cosf(arg) : sinf(arg);
+  }
+  if (out_bf16) ((unsigned short*)out)[(long)i * dim + j] = f32_to_bf16(val);
+  else ((float*)out)[(long)i * dim + j] = val;
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f32_to_bf16(silu_f(x[i]));
+}
+
+// one thread per (u, t, pixel): gathers 4 + Cc channel planes (NCHW fp32) into a
+// padded channels-last bf16 row
+__global__ void cfg_prepare_kernel(const float* __restrict__ x, const float* __restrict__ cu,
+                                   const float* __restrict__ cc, unsigned short* __restrict__ out,
+                                   int T, int HW, int Cc, int Cp, float c_in) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = 2L * T * HW;
+  if (idx >= total) return;
+  const int p = (int)(idx % HW); const int t = (int)((idx / HW) % T); const int u = (int)(idx / ((long)HW * T));
+  unsigned short* o = out + idx * Cp;
+  const float* xs = x + (long)t * 4 * HW + p;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = f32_to_bf16(xs[(long)c * HW] * c_in);
+  const float* cs = u ? cc : cu;
+  for (int c = 0; c < Cc; ++c) o[4 + c] = cs ? f32_to_bf16(cs[((long)t * Cc + c) * HW + p]) : (unsigned short)0;
+  for (int c = 4 + Cc; c < Cp; ++c) o[c] = 0;
+}
+
+__global__ void sampler_step_kernel(float* __restrict__ x, const float* __restrict__ net,
+                                    const float* __restrict__ scale, int T, int HW, int ldn,
+                                    float c_skip, float c_out, float dt_over_sigma) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * HW;
+  if (idx >= total) return;
+  const int p = (int)(idx % HW), t = (int)(idx / HW);
+  const float* nu = net + idx * ldn;
+  const float* nc = net + (total + idx) * ldn;
+  const float s = scale[t];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float* xp = x + ((long)t * 4 + c) * HW + p;
+    const float xv = *xp;
+    const float du = nu[c] * c_out + xv * c_skip;
+    const float dc = nc[c] * c_out + xv * c_skip;
+    const float d = du + s * (dc - du);
+    *xp = xv + dt_over_sigma * (xv - d);
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                    int C, int HW, int Cpad, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over N*HW*Cpad
+  if (idx >= total) return;
+  const int c = (int)(idx % Cpad); const long np = idx / Cpad;
+  const int p = (int)(np % HW); const long n = np / HW;
+  y[idx] = c < C ? f32_to_bf16(x[(n * C + c) * HW + p]) : (unsigned short)0;
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y, int C, int HW,
+                                    int ldx, int x_is_f32, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over N*C*HW (output order)
+  if (idx >= total) return;
+  const int p = (int)(idx % HW); const long nc = idx / HW;
+  const int c = (int)(nc % C); const long n = nc / C;
+  const long src = (n * HW + p) * ldx + c;
+  y[idx] = x_is_f32 ? ((const float*)x)[src] : bf16_to_f32(((const unsigned short*)x)[src]);
+}
+
+inline unsigned grid_for(long n, int block, long cap = 65536) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int hi3d_concat_channels(const void* a, const void* b, void* out, int64_t rows,
+                                    int32_t C0, int32_t C1, void* stream) {
+  if (!a || !b || !out) HI3D_FAIL(HI3D_EINVAL, "concat: null pointer");
+  if (rows <= 0 || C0 <= 0 || C1 <= 0) HI3D_FAIL(HI3D_EINVAL, "concat: non-positive size");
+  if ((C0 % 8) || (C1 % 8)) HI3D_FAIL(HI3D_ESHAPE, "concat: channel counts must be multiples of 8");
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) HI3D_FAIL(HI3D_EALIGN, "concat: misaligned pointer");
+  const long total = rows * ((C0 + C1) / 8);
+  hipLaunchKernelGGL(concat_channels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)a, (const uint4*)b, (uint4*)out, (long)rows, C0 / 8, C1 / 8);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
+                                       float max_period, int32_t out_bf16, void* stream) {
+  if (!t || !out) HI3D_FAIL(HI3D_EINVAL, "timestep_embedding: null pointer");
+  if (n <= 0 || dim < 2 || max_period <= 0.f) HI3D_FAIL(HI3D_EINVAL, "timestep_embedding: bad size");
+  const int half = dim / 2;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(n, (dim + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     t, out, n, dim, -logf(max_period) / (float)half, out_bf16);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  if (!x || !y) HI3D_FAIL(HI3D_EINVAL, "silu: null pointer");
+  if (n <= 0) HI3D_FAIL(HI3D_EINVAL, "silu: non-positive size");
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, (long)n);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_cfg_prepare(const float* x, const float* concat_uc, const float* concat_c, void* out,
+                                int32_t T, int32_t HW, int32_t Cc, int32_t Cp, float sigma, void* stream) {
+  if (!x || !out) HI3D_FAIL(HI3D_EINVAL, "cfg_prepare: null pointer");
+  if (T <= 0 || HW <= 0 || Cc < 0 || Cp < 4 + Cc) HI3D_FAIL(HI3D_EINVAL, "cfg_prepare: bad size");
+  if (sigma < 0.f) HI3D_FAIL(HI3D_EINVAL, "cfg_prepare: negative sigma");
+  const float c_in = 1.0f / sqrtf(sigma * sigma + 1.0f);
+  const long total = 2L * T * HW;
+  hipLaunchKernelGGL(cfg_prepare_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, concat_uc, concat_c, (unsigned short*)out, T, HW, Cc, Cp, c_in);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_sampler_step(float* x, const float* net, const float* scale, int32_t T, int32_t HW,
+                                 int32_t ldn, float sigma, float sigma_next, void* stream) {
+  if (!x || !net || !scale) HI3D_FAIL(HI3D_EINVAL, "sampler_step: null pointer");
+  if (T <= 0 || HW <= 0 || ldn < 4) HI3D_FAIL(HI3D_EINVAL, "sampler_step: bad size");
+  if (!(sigma > 0.f)) HI3D_FAIL(HI3D_EINVAL, "sampler_step: sigma must be > 0");
+  const float c_skip = 1.0f / (sigma * sigma + 1.0f);
+  const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
+  const float dt_over_sigma = (sigma_next - sigma) / sigma;
+  const long total = (long)T * HW;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, net, scale, T, HW, ldn, c_skip, c_out, dt_over_sigma);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t HW,
+                                          int32_t Cpad, void* stream) {
+  if (!x || !y) HI3D_FAIL(HI3D_EINVAL, "nchw_to_nhwc: null pointer");
+  if (N <= 0 || C <= 0 || HW <= 0 || Cpad < C) HI3D_FAIL(HI3D_EINVAL, "nchw_to_nhwc: bad size");
+  const long total = (long)N * HW * Cpad;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, (unsigned short*)y, C, HW, Cpad, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_nhwc_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t HW,
+                                     int32_t ldx, int32_t x_is_f32, void* stream) {
+  if (!x || !y) HI3D_FAIL(HI3D_EINVAL, "nhwc_to_nchw: null pointer");
+  if (N <= 0 || C <= 0 || HW <= 0 || ldx < C) HI3D_FAIL(HI3D_EINVAL, "nhwc_to_nchw: bad size");
+  const long total = (long)N * C * HW;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, C, HW, ldx, x_is_f32, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}

@@ -1,0 +1,245 @@
+// GroupNorm(32)+SiLU and LayerNorm for channels-last bf16 activations (gfx950).
+// Both are HBM-bound: 16-byte vector loads/stores, fp32 statistics, one read of x
+// for the statistics and one read + one write for the normalisation.
+//
+// GroupNorm works on x[inst][P][C]; an (instance, group) spans P pixels x C/32
+// channels.  The 2-D ResBlock norm is inst = frames, P = H*W; the 3-D time_stack norm
+// (statistics over t,h,w -- sgm/modules/diffusionmodules/video_model.py:71-76) is the
+// same memory viewed as inst = b, P = T*H*W: no permute is ever materialised.
+//   pass 1  gn_stats    : per-block partial (sum, sumsq) per group      -> ws
+//   pass 2  gn_finalize : fixed-order fp64 combine -> (mean, rstd)      -> ws
+//   pass 3  gn_apply    : y = silu(x * a_c + b_c), a_c = rstd*gamma_c, b_c = beta_c - mean*a_c
+// Fixed summation order => bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_PPB = 512;        // pixels per stats block
+constexpr int GN_APPLY_PPB = 128;  // pixels per apply block
+
+__host__ __device__ inline int gn_threads(int C) {
+  const int vec = C / 8;                       // 16-byte vectors per pixel
+  if (vec >= 256) return vec;                  // one pixel per sweep
+  return vec * (256 / vec);                    // whole pixels per sweep, <= 256 threads
+}
+
+__global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial,
+                                int P, int C, int nblk) {
+  __shared__ float gs[64];
+  const int vec = C >> 3, cpg = C >> 5;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
+  const int inst = blockIdx.y, blk = blockIdx.x;
+  const int p_begin = blk * GN_PPB, p_end = min(P, p_begin + GN_PPB);
+  const uint4* base = x + (long)inst * P * vec;
+  float s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+  for (int p = p_begin + rsub; p < p_end; p += rows_per_sweep) {
+    const uint4 v = base[(long)p * vec + chunk];
+    const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16_to_f32(u[j] & 0xffff), b = bf16_to_f32(u[j] >> 16);
+      s[2 * j] += a; ss[2 * j] += a * a;
+      s[2 * j + 1] += b; ss[2 * j + 1] += b * b;
+    }
+  }
+  // fixed-order reduction: every thread parks its 8 per-channel sums in LDS, then
+  // thread (group, sum|sumsq) walks its group's channels and pixel sub-rows in order.
+  extern __shared__ float red[];            // [nthr][16]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = ss[j]; }
+  __syncthreads();
+  if (tid < 64) {
+    const int g = tid >> 1, which = tid & 1;
+    float acc = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const int ch = c >> 3, j = c & 7;
+      for (int r = 0; r < rows_per_sweep; ++r) acc += red[(r * vec + ch) * 16 + which * 8 + j];
+    }
+    gs[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) partial[((long)inst * nblk + blk) * 64 + tid] = gs[tid];
+}
+
+// one block of 64 threads per instance: thread = (group, {sum|sumsq})
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                   int nblk, double inv_count, float eps) {
+  const int inst = blockIdx.x, tid = threadIdx.x;
+  double acc = 0.0;
+  for (int b = 0; b < nblk; ++b) acc += (double)partial[((long)inst * nblk + b) * 64 + tid];
+  __shared__ double sh[64];
+  sh[tid] = acc;
+  __syncthreads();
+  if ((tid & 1) == 0) {
+    const double mean = sh[tid] * inv_count;
+    double var = sh[tid + 1] * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[inst * 64 + tid] = (float)mean;
+    stats[inst * 64 + tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <bool SILU>
+__global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ stats, int P, int C) {
+  const int vec = C >> 3, cpg = C >> 5;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
+  const int inst = blockIdx.y;
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = chunk * 8 + j, g = c / cpg;
+    const float mean = stats[inst * 64 + g * 2], rstd = stats[inst * 64 + g * 2 + 1];
+    a[j] = rstd * gamma[c];
+    b[j] = beta[c] - mean * a[j];
+  }
+  const int p_begin = blockIdx.x * GN_APPLY_PPB, p_end = min(P, p_begin + GN_APPLY_PPB);
+  const long base = (long)inst * P * vec;
+  for (int p = p_begin + rsub; p < p_end; p += rows_per_sweep) {
+    const long idx = base + (long)p * vec + chunk;
+    const uint4 v = x[idx];
+    const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+    unsigned int o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = bf16_to_f32(u[j] & 0xffff) * a[2 * j] + b[2 * j];
+      float hi = bf16_to_f32(u[j] >> 16) * a[2 * j + 1] + b[2 * j + 1];
+      if (SILU) { lo = silu_f(lo); hi = silu_f(hi); }
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    y[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- LayerNorm: one wave per row, up to 4 16-byte vectors per lane (C <= 2048)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const uint4* __restrict__ x, uint4* __restrict__ y, uint4* __restrict__ sum_out,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ addvec, int rpg, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int vec = C >> 3;
+  const uint4* xr = x + row * vec;
+  const float* av = addvec ? addvec + (row / rpg) * (long)C : nullptr;
+  float f[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vec) {
+      const uint4 q = xr[v];
+      const unsigned int u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[i][2 * j] = bf16_to_f32(u[j] & 0xffff);
+        f[i][2 * j + 1] = bf16_to_f32(u[j] >> 16);
+      }
+      if (av) {
+        const f32x4 a0 = *(const f32x4*)(av + v * 8), a1 = *(const f32x4*)(av + v * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[i][j] += a0[j]; f[i][4 + j] += a1[j]; }
+        if (sum_out) {
+          sum_out[row * vec + v] = make_uint4(pack_bf16x2(f[i][0], f[i][1]), pack_bf16x2(f[i][2], f[i][3]),
+                                              pack_bf16x2(f[i][4], f[i][5]), pack_bf16x2(f[i][6], f[i][7]));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (lane + i * 64 < vec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = lane + i * 64;
+    if (v < vec) {
+      const f32x4 g0 = *(const f32x4*)(gamma + v * 8), g1 = *(const f32x4*)(gamma + v * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + v * 8), b1 = *(const f32x4*)(beta + v * 8 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+        o[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      y[row * vec + v] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                    pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t hi3d_gn_partial_blocks(int32_t P, int32_t C) {
+  (void)C;
+  return (P + GN_PPB - 1) / GN_PPB;
+}
+
+extern "C" int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C) {
+  return (int64_t)inst * hi3d_gn_partial_blocks(P, C) * 64 + (int64_t)inst * 64;
+}
+
+extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
+                                   float* ws, int32_t inst, int32_t P, int32_t C, float eps,
+                                   int32_t apply_silu, void* stream) {
+  if (!x || !y || !gamma || !beta || !ws) HI3D_FAIL(HI3D_EINVAL, "groupnorm: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = hi3d_gn_partial_blocks(P, C);
+  float* partial = ws;
+  float* stats = ws + (long)inst * nblk * 64;
+  const int nthr = gn_threads(C);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, partial, P, C, nblk);
+  HI3D_LAUNCH_CHECK();
+  const double inv_count = 1.0 / ((double)P * (double)(C / 32));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64), 0, s, partial, stats, nblk, inv_count, eps);
+  HI3D_LAUNCH_CHECK();
+  const int ablk = (P + GN_APPLY_PPB - 1) / GN_APPLY_PPB;
+  if (apply_silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_layernorm(const void* x, void* y, void* sum_out, const float* gamma,
+                              const float* beta, const float* addvec, int32_t rows_per_group,
+                              int32_t R, int32_t C, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta) HI3D_FAIL(HI3D_EINVAL, "layernorm: null pointer");
+  if (R <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "layernorm: non-positive size");
+  if (C % 8 || C > 2048) HI3D_FAIL(HI3D_ESHAPE, "layernorm: C must be a multiple of 8 and <= 2048");
+  if (addvec && rows_per_group < 1) HI3D_FAIL(HI3D_EINVAL, "layernorm: rows_per_group < 1");
+  if (sum_out && !addvec) HI3D_FAIL(HI3D_EINVAL, "layernorm: sum_out without addvec");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)sum_out) & 15) HI3D_FAIL(HI3D_EALIGN, "layernorm: not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (R + 3) / 4, vec = C / 8;
+  const int rpg = rows_per_group < 1 ? 1 : rows_per_group;
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(grid), dim3(256), 0, s, (const uint4*)x, (uint4*)y, (uint4*)sum_out, gamma, beta, addvec, rpg, R, C, eps)
+  if (vec <= 64) LN_LAUNCH(1);
+  else if (vec <= 128) LN_LAUNCH(2);
+  else if (vec <= 192) LN_LAUNCH(3);
+  else LN_LAUNCH(4);
+#undef LN_LAUNCH
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}

@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI: torch supplies device memory and the
+current HIP stream, every FLOP runs in libhi3d_hip.so.
+
+Activations: torch.bfloat16, channels-last tokens [frames, H*W, C] (contiguous).
+"""
+import torch
+
+from . import lib as _l
+
+_lib = _l.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.Hi3dError("hi3d ops need device tensors (got a CPU tensor); there is no CPU path")
+
+
+def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
+         R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
+         lda=None, conv3x3=None, convt3=None, tile_n=0):
+    """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
+
+    conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
+    """
+    _chk_dev(A, W, out, bias, rowvec, R1, R2, a1, a2)
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=A.device, dtype=torch.float32 if out_fp32 else torch.bfloat16)
+    d = _l.GemmDesc()
+    d.A, d.W, d.bias, d.rowvec = _p(A), _p(W), _p(bias), _p(rowvec)
+    d.R1, d.R2, d.a1, d.a2, d.out = _p(R1), _p(R2), _p(a1), _p(a2), _p(out)
+    d.M, d.N, d.K = M, N, K
+    d.lda = K if lda is None else lda
+    d.ldo = out.stride(0) if out.dim() == 2 else n_out
+    d.ldr1 = R1.stride(-2) if R1 is not None else 0
+    d.ldr2 = R2.stride(-2) if R2 is not None else 0
+    d.ldrv = ldrv
+    d.rows_per_group = rows_per_group
+    d.epi = _l.EPI_GEGLU if geglu else _l.EPI_AFFINE
+    d.out_fp32 = 1 if out_fp32 else 0
+    d.tile_n = tile_n
+    if conv3x3 is not None:
+        d.amode = _l.A_CONV3X3
+        for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "up2x"):
+            setattr(d, k, int(conv3x3[k]))
+    elif convt3 is not None:
+        d.amode = _l.A_CONVT3
+        d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])
+    else:
+        d.amode = _l.A_DENSE
+    _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")
+    return out
+
+
+def transpose_v(v_view, B, H, S, ldv):
+    """v_view: tensor whose data_ptr is V[b=0,s=0,h=0,d=0]; returns vt [B,H,64,S_pad]."""
+    S_pad = (S + 63) // 64 * 64
+    vt = torch.empty((B, H, 64, S_pad), device=v_view.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_transpose_v(_p(v_view), _p(vt), B, H, S, S_pad, ldv, _stream()), "hi3d_transpose_v")
+    return vt
+
+
+def attention_d64(q, k, vt, B, H, S_q, S_kv, ldq, ldk, scale, out=None):
+    _chk_dev(q, k, vt, out)
+    if out is None:
+        out = torch.empty((B * S_q, H * 64), device=q.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_attn_d64(_p(q), _p(k), _p(vt), _p(out), B, H, S_q, S_kv, ldq, ldk,
+                                vt.shape[-1], out.stride(0), float(scale), _stream()), "hi3d_attn_d64")
+    return out
+
+
+def self_attention_fused_qkv(qkv, B, S, H, scale=None):
+    """qkv: [B*S, 3*H*64] bf16 (q | k | v column blocks). Returns [B*S, H*64]."""
+    C = H * 64
+    assert qkv.shape == (B * S, 3 * C) and qkv.is_contiguous()
+    scale = 64 ** -0.5 if scale is None else scale
+    vt = transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+    return attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
+
+
+def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
+    """qkv: [(B*T*S), 3*H*64] bf16 in frame-major (b t s) row order."""
+    C = H * 64
+    assert qkv.shape == (B * T * S, 3 * C) and qkv.is_contiguous()
+    scale = 64 ** -0.5 if scale is None else scale
+    out = torch.empty((B * T * S, C), device=qkv.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_attn_temporal_d64(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), _p(out),
+                                         B, T, S, H, 3 * C, C, float(scale), _stream()),
+             "hi3d_attn_temporal_d64")
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
+    """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32)."""
+    _chk_dev(x, gamma, beta, out)
+    assert x.is_contiguous() and x.numel() == inst * P * C
+    if out is None:
+        out = torch.empty_like(x)
+    n = _lib.hi3d_gn_workspace_floats(inst, P, C)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 16), device=x.device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    _l.check(_lib.hi3d_groupnorm_silu(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
+                                      float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu")
+    return out
+
+
+def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum_out=None, out=None):
+    _chk_dev(x, gamma, beta, addvec, sum_out, out)
+    if out is None:
+        out = torch.empty((R, C), device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_layernorm(_p(x), _p(out), _p(sum_out), _p(gamma), _p(beta), _p(addvec),
+                                 rows_per_group, R, C, float(eps), _stream()), "hi3d_layernorm")
+    return out
+
+
+def concat_channels(a, b, rows, C0, C1):
+    out = torch.empty((rows, C0 + C1), device=a.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_concat_channels(_p(a), _p(b), _p(out), rows, C0, C1, _stream()), "hi3d_concat_channels")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0, out_bf16=False):
+    t = t.to(torch.float32).contiguous()
+    _chk_dev(t)
+    out = torch.empty((t.numel(), dim), device=t.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _l.check(_lib.hi3d_timestep_embedding(_p(t), _p(out), t.numel(), dim, float(max_period),
+                                          1 if out_bf16 else 0, _stream()), "hi3d_timestep_embedding")
+    return out
+
+
+def silu_to_bf16(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_silu_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "hi3d_silu_f32_to_bf16")
+    return out
+
+
+def cfg_prepare(x, concat_uc, concat_c, Cp, sigma):
+    """x: fp32 [T,4,H,W]; concat_*: fp32 [T,Cc,H,W] or None -> bf16 [2*T*HW, Cp]."""
+    T, _, H, W = x.shape
+    Cc = 0 if concat_c is None else concat_c.shape[1]
+    out = torch.empty((2 * T * H * W, Cp), device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_cfg_prepare(_p(x), _p(concat_uc), _p(concat_c), _p(out), T, H * W, Cc, Cp,
+                                   float(sigma), _stream()), "hi3d_cfg_prepare")
+    return out
+
+
+def sampler_step(x, net, scale, ldn, sigma, sigma_next):
+    T, _, H, W = x.shape
+    _l.check(_lib.hi3d_sampler_step(_p(x), _p(net), _p(scale), T, H * W, ldn, float(sigma),
+                                    float(sigma_next), _stream()), "hi3d_sampler_step")
+    return x
+
+
+def nchw_to_tokens(x, Cpad):
+    """fp32 NCHW -> bf16 [N*HW, Cpad] (zero padded channels)."""
+    x = x.to(torch.float32).contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N * H * W, Cpad), device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_nchw_f32_to_nhwc_bf16(_p(x), _p(out), N, Cc, H * W, Cpad, _stream()),
+             "hi3d_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def tokens_to_nchw(x, N, Cc, H, W, ldx):
+    out = torch.empty((N, Cc, H, W), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_nhwc_to_nchw_f32(_p(x), _p(out), N, Cc, H * W, ldx,
+                                        1 if x.dtype == torch.float32 else 0, _stream()),
+             "hi3d_nhwc_to_nchw_f32")
+    return out

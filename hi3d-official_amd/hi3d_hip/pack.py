@@ -1,0 +1,65 @@
+"""One-time weight re-layout: reference state_dict tensors (OIHW / OIDHW / [out,in],
+fp32 or fp16) -> the K-major bf16 images the gfx950 GEMM consumes.
+
+All functions are pure tensor reshuffles on whatever device the input lives on.
+"""
+import torch
+
+
+def _bf16(w):
+    return w.detach().to(torch.bfloat16).contiguous()
+
+
+def pack_linear(w):
+    """nn.Linear weight [N, K] is already K-major."""
+    return _bf16(w)
+
+
+def pack_conv1x1(w):
+    """[O, I, 1, 1] -> [O, I]"""
+    return _bf16(w.reshape(w.shape[0], w.shape[1]))
+
+
+def pack_conv3x3(w, cin_pad=None, cout_pad=None):
+    """OIHW [O, I, 3, 3] -> [O_pad, (ky, kx, I_pad)]: k = (ky*3+kx)*I_pad + ci."""
+    O, I = w.shape[:2]
+    Ip = I if cin_pad is None else cin_pad
+    Op = O if cout_pad is None else cout_pad
+    out = torch.zeros((Op, 3, 3, Ip), dtype=torch.bfloat16, device=w.device)
+    out[:O, :, :, :I] = w.detach().permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out.reshape(Op, 9 * Ip).contiguous()
+
+
+def pack_convt3(w):
+    """Conv3d (3,1,1) weight [O, I, 3, 1, 1] -> [O, (kt, I)]."""
+    O, I = w.shape[:2]
+    return _bf16(w.reshape(O, I, 3).permute(0, 2, 1).reshape(O, 3 * I))
+
+
+def pack_geglu(w, b):
+    """GEGLU proj [2*inner, K] (first half = value, second half = gate,
+    sgm/modules/attention.py:92-94) -> rows ordered [x0, x1, g0, g1] per 4 rows so the
+    MFMA epilogue finds value and gate of the same output column in one lane."""
+    two_inner, K = w.shape
+    inner = two_inner // 2
+    assert inner % 2 == 0
+    wx, wg = w[:inner].reshape(inner // 2, 2, K), w[inner:].reshape(inner // 2, 2, K)
+    wp = torch.cat([wx, wg], dim=1).reshape(two_inner, K)
+    bx, bg = b[:inner].reshape(inner // 2, 2), b[inner:].reshape(inner // 2, 2)
+    bp = torch.cat([bx, bg], dim=1).reshape(two_inner)
+    return _bf16(wp), bp.detach().to(torch.float32).contiguous()
+
+
+def pack_qkv(wq, wk, wv):
+    """to_q / to_k / to_v (bias-free, attention.py:272-274) -> one [3C, C] matrix."""
+    return _bf16(torch.cat([wq, wk, wv], dim=0))
+
+
+def f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pad_vec(b, n):
+    out = torch.zeros((n,), dtype=torch.float32, device=b.device)
+    out[: b.numel()] = b.detach().to(torch.float32)
+    return out

@@ -1,0 +1,212 @@
+/*
+ * hi3d_hip.h -- C ABI of libhi3d_hip.so: the MI355X (gfx950 / CDNA4) operator
+ * library behind the Hi3D denoising hot path (VideoUNet sampler + VAE decode).
+ *
+ * The reference (yanghb22-fdu/Hi3D-Official) has NO native boundary on this
+ * path: every hot operator is a torch.nn / xformers call.
+ * The seam it does have is the operator-plugin point it already uses to swap
+ * SDPA <-> xformers (sgm/modules/attention.py:457-460 ATTENTION_MODES,
+ * sgm/modules/diffusionmodules/model.py:277-309 make_attn) plus the YAML
+ * `target:` registry (sgm/util.py:168-185).  Each entry point below names the
+ * reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless said
+ *     otherwise; `stream` is a hipStream_t passed as void*.
+ *   - return 0 on success, negative HI3D_E* on invalid arguments / unsupported
+ *     shapes (nothing is launched in that case), positive = hipError_t of the
+ *     failed launch.  Nothing throws across the ABI.
+ *   - activations are channels-last "token" tensors [frames, H*W, C] in bf16
+ *     (raw uint16 storage), statistics / accumulators fp32.
+ *   - the library never allocates persistent device memory; workspaces are
+ *     caller-owned.  All entry points are re-entrant and stateless, hence
+ *     HIP-graph capturable.
+ */
+#ifndef HI3D_HIP_H
+#define HI3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HI3D_OK 0
+#define HI3D_EINVAL -1      /* null pointer / negative size / bad enum        */
+#define HI3D_ESHAPE -2      /* shape not supported by the gfx950 kernels      */
+#define HI3D_EALIGN -3      /* pointer / leading dimension alignment          */
+
+#define HI3D_ABI_VERSION 1
+int hi3d_abi_version(void);
+/* static description of the last error on this host thread (never NULL) */
+const char* hi3d_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* GEMM / implicit-GEMM convolution on bf16 MFMA (v_mfma_f32_16x16x32_bf16)  */
+/* ------------------------------------------------------------------------ */
+/* out[m, n] = a1[g(m)] * ( sum_k A(m,k) * W[n,k] + bias[n] + rowvec[g(m), n]
+ *                          + R1[m, n] ) + a2[g(m)] * R2[m, n]
+ *   g(m) = m / rows_per_group ; absent (NULL) terms are skipped, a1 defaults
+ *   to 1 and a2 to 1 (R2 is only added when non-NULL).
+ *
+ * A(m,k) is produced by one of three gather modes (never materialised):
+ *   HI3D_A_DENSE   A is [M, lda] row-major; nn.Linear
+ *                  (sgm/modules/attention.py:87-113,272-278,675,699;
+ *                   sgm/modules/video_attention.py:50-54,71,220-224;
+ *                   sgm/modules/diffusionmodules/video_model.py:151-182;
+ *                   openaimodel.py:284-290 emb_layers; 1x1 conv openaimodel.py:314)
+ *   HI3D_A_CONV3X3 3x3 convolution, padding 1, on NHWC input [frames,Hin,Win,Cin];
+ *                  m enumerates output pixels (frame, oy, ox); k = (ky*3+kx)*Cin+ci.
+ *                  stride 1|2 (openaimodel.py:192-199 Downsample), optional
+ *                  nearest-2x upsample folded into the gather
+ *                  (openaimodel.py:154-156 ; model.py:67-71).
+ *                  (openaimodel.py:257-261,292-305 ResBlock convs; video_model.py:189,439)
+ *   HI3D_A_CONVT3  temporal Conv3d kernel (3,1,1), padding (1,0,0), on
+ *                  [(b t), HW, Cin]; k = kt*Cin+ci (video_model.py:42-55 time_stack
+ *                  -> openaimodel.py:257-261,296-304 with dims=3).
+ *
+ * Epilogues:
+ *   HI3D_EPI_AFFINE  as written above.
+ *   HI3D_EPI_GEGLU   W/bias rows are packed [x0,x1,g0,g1] per 4 rows; writes
+ *                    N/2 columns  out = (x+bx) * gelu_erf(g+bg)
+ *                    (sgm/modules/attention.py:87-94 GEGLU).
+ *
+ * Requirements: K % 64 == 0, N % 4 == 0, Cin % 64 == 0 for the conv modes
+ * (pad tiny channel counts with zeros), 16-byte aligned A/W rows.
+ */
+enum { HI3D_A_DENSE = 0, HI3D_A_CONV3X3 = 1, HI3D_A_CONVT3 = 2 };
+enum { HI3D_EPI_AFFINE = 0, HI3D_EPI_GEGLU = 1 };
+
+typedef struct hi3d_gemm_desc {
+  const void* A;        /* bf16 activations (layout per amode)                */
+  const void* W;        /* bf16 [N][K], K contiguous                          */
+  const float* bias;    /* [N] or NULL                                        */
+  const float* rowvec;  /* [M/rows_per_group][ldrv] fp32 or NULL              */
+  const void* R1;       /* bf16 [M][ldr1] or NULL                             */
+  const void* R2;       /* bf16 [M][ldr2] or NULL                             */
+  const float* a1;      /* [M/rows_per_group] or NULL (=1)                    */
+  const float* a2;      /* [M/rows_per_group] or NULL (=1)                    */
+  void* out;            /* bf16 (or fp32 if out_fp32) [M][ldo]                */
+  int32_t M, N, K;
+  int32_t lda, ldo, ldr1, ldr2;  /* in elements                               */
+  int32_t ldrv;                  /* row stride of rowvec (0 = N)              */
+  int32_t rows_per_group;        /* >=1                                       */
+  int32_t amode, epi, out_fp32;
+  /* conv3x3: */
+  int32_t Hin, Win, Cin, Hout, Wout, stride, up2x;
+  /* convt3:  (Cin shared) */
+  int32_t T, HW;
+  int32_t tile_n;       /* 0 = auto, else 128 or 160                          */
+} hi3d_gemm_desc;
+
+int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Attention                                                                 */
+/* ------------------------------------------------------------------------ */
+/* Flash-style softmax(Q K^T * scale) V, head dim 64, bf16 in/out, fp32
+ * accumulate; replaces F.scaled_dot_product_attention / xformers
+ * memory_efficient_attention at sgm/modules/attention.py:332-336,427-439.
+ *   q, k : rows of 64 contiguous bf16 at
+ *          base + (b*S + s)*ld + h*64      (heads interleaved "(h d)")
+ *   vt   : V transposed per head, [B][H][64][S_pad] bf16 (see hi3d_transpose_v)
+ *   out  : [B][S][ldo] with head h at column h*64
+ * S_kv keys are attended by S_q queries (self-attention: equal).            */
+int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
+                  int32_t B, int32_t H, int32_t S_q, int32_t S_kv,
+                  int32_t ldq, int32_t ldk, int32_t ld_vt /* = S_pad */, int32_t ldo,
+                  float scale, void* stream);
+
+/* vt[b][h][d][s] = v[(b*S+s)*ldv + h*64 + d]  ; S_pad % 64 == 0, pad = 0    */
+int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
+                     int32_t S_pad, int32_t ldv, void* stream);
+
+/* Temporal self-attention over the frame axis at every pixel
+ * (sgm/modules/video_attention.py:114-125: "(b t) s c -> (b s) t c" then
+ * attn1).  Reads q/k/v straight from the frame-major token layout -- the
+ * reference's two permutes never happen.
+ *   q,k,v element (b,t,s,h,d) at base + ((b*T+t)*S + s)*ld + h*64 + d
+ *   T <= 32.                                                                */
+int hi3d_attn_temporal_d64(const void* q, const void* k, const void* v, void* out,
+                           int32_t B, int32_t T, int32_t S, int32_t H,
+                           int32_t ldqkv, int32_t ldo, float scale, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Normalisation                                                             */
+/* ------------------------------------------------------------------------ */
+/* GroupNorm(32 groups) statistics + fused affine + optional SiLU on
+ * channels-last input x[inst][P][C]; statistics span the P*C/32 elements of
+ * each (instance, group) in fp32 (sgm/modules/diffusionmodules/util.py:259-276
+ * GroupNorm32; eps 1e-5 in ResBlocks openaimodel.py:257-259,292-294; eps 1e-6
+ * sgm/modules/attention.py:125-128 and model.py:52-55).  2-D ResBlocks call it
+ * with inst = frames, P = H*W; the 3-D time_stack (video_model.py:71-76) with
+ * inst = b, P = T*H*W -- same memory, no permute.
+ *   ws : caller workspace of hi3d_gn_workspace_floats(inst, P, C) floats (partial
+ *        sums + per-instance mean/rstd); contents are scratch.               */
+int32_t hi3d_gn_partial_blocks(int32_t P, int32_t C);
+int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C);
+int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
+                        float* ws, int32_t inst, int32_t P, int32_t C,
+                        float eps, int32_t apply_silu, void* stream);
+
+/* LayerNorm over the last dim C of x[R][C] (sgm/modules/attention.py:520-522;
+ * video_attention.py:51,79,93-94), with an optional fused per-group pre-add:
+ *   s = x[r] + addvec[r / rows_per_group]   (addvec fp32 [G][C] or NULL)
+ *   if sum_out: sum_out[r] = s (bf16; may alias x)
+ *   y[r] = LN(s) * gamma + beta
+ * (the pre-add is the frame-position embedding of video_attention.py:286-287). */
+int hi3d_layernorm(const void* x, void* y, void* sum_out, const float* gamma,
+                   const float* beta, const float* addvec, int32_t rows_per_group,
+                   int32_t R, int32_t C, float eps, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Layout / elementwise                                                      */
+/* ------------------------------------------------------------------------ */
+/* out[f][p][0:C0] = a[f][p][:], out[f][p][C0:C0+C1] = b[f][p][:]  (th.cat of
+ * video_model.py:491 on channels-last data)                                 */
+int hi3d_concat_channels(const void* a, const void* b, void* out, int64_t rows,
+                         int32_t C0, int32_t C1, void* stream);
+
+/* Sinusoidal embedding cos||sin (util.py:207-231): out[i][0:half]=cos(t_i f_j),
+ * out[i][half:]=sin ; f_j = exp(-ln(max_period) j / half).  out fp32 or bf16. */
+int hi3d_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
+                            float max_period, int32_t out_bf16, void* stream);
+
+/* y = silu(x) elementwise fp32 -> bf16 (emb_layers' leading SiLU,
+ * openaimodel.py:284-286), n elements                                        */
+int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* Build the UNet input for one CFG-doubled step (guiders.py:88-99 prepare_inputs,
+ * denoiser.py:36-37 `input * c_in`, wrappers.py:26 cat with c["concat"]) directly
+ * in padded channels-last bf16:
+ *   out[u][t][p][0:4]      = x[t][0:4][p] * c_in(sigma)      u = 0 (uncond), 1 (cond)
+ *   out[u][t][p][4:4+Cc]   = concat_u[t][0:Cc][p]            (NCHW fp32 inputs)
+ *   out[u][t][p][4+Cc:Cp]  = 0
+ * x: fp32 NCHW [T][4][HW]; concat_uc / concat_c: fp32 NCHW [T][Cc][HW] or NULL */
+int hi3d_cfg_prepare(const float* x, const float* concat_uc, const float* concat_c,
+                     void* out, int32_t T, int32_t HW, int32_t Cc, int32_t Cp,
+                     float sigma, void* stream);
+
+/* One fused Euler-EDM update with linear-prediction CFG:
+ *   D_u = net_u * c_out + x * c_skip ; D_c likewise   (denoiser.py:36-39,
+ *                                                      denoiser_scaling.py:51-59)
+ *   D   = D_u + scale[t] * (D_c - D_u)                 (guiders.py:78-86)
+ *   x  <- x + (sigma_next - sigma) * (x - D) / sigma   (sampling.py:93-107,
+ *                                                      sampling_utils.py:34-35)
+ * net: fp32 channels-last [2][T][HW][ldn] (first 4 columns used);
+ * x: fp32 NCHW [T][4][HW] updated in place.                                  */
+int hi3d_sampler_step(float* x, const float* net, const float* scale, int32_t T,
+                      int32_t HW, int32_t ldn, float sigma, float sigma_next,
+                      void* stream);
+
+/* NCHW fp32 <-> channels-last bf16 converters used at the module boundary
+ * (VideoUNet.forward keeps the reference's NCHW signature).                  */
+int hi3d_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t HW,
+                               int32_t Cpad, void* stream);
+int hi3d_nhwc_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t HW,
+                          int32_t ldx, int32_t x_is_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HI3D_HIP_H */

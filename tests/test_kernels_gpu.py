@@ -1,0 +1,242 @@
+"""Per-kernel parity: every C-ABI entry point vs a plain PyTorch fp32 CPU reference of
+the same op on identical (bf16-rounded) inputs.  Tolerances are stated per test:
+outputs are stored in bf16 (rel. step 2^-8 = 3.9e-3), accumulation is fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+BF16_TOL = 1.2e-2   # max-abs error / max-abs reference for a bf16-stored result
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(300, 320, 320, 0), (1000, 128, 64, 128), (128, 960, 640, 160),
+                                        (77, 4, 128, 0), (513, 640, 1280, 0), (256, 1280, 320, 128)])
+def test_gemm_dense_full_epilogue(dev, M, N, K, tile):
+    from hi3d_hip import ops
+    rpg = 50
+    G = (M + rpg - 1) // rpg
+    A, W = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, K ** -0.5))
+    bias, rowvec = rnd((N,), 3), rnd((G, N + 4), 4)
+    R1, R2 = bf(rnd((M, N), 5)), bf(rnd((M, N), 6))
+    a1, a2 = rnd((G,), 7).abs() + 0.5, rnd((G,), 8)
+    grp = torch.arange(M) // rpg
+    ref = (A.float() @ W.float().T + bias + rowvec[grp, :N] + R1.float()) * a1[grp, None] + a2[grp, None] * R2.float()
+    out = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K, bias=bias.to(dev), rowvec=rowvec.to(dev), ldrv=N + 4,
+                   rows_per_group=rpg, R1=R1.to(dev), R2=R2.to(dev), a1=a1.to(dev), a2=a2.to(dev), tile_n=tile)
+    assert relerr(out, ref) < BF16_TOL
+    out32 = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K, bias=bias.to(dev), out_fp32=True, tile_n=tile)
+    assert relerr(out32, A.float() @ W.float().T + bias) < 2e-5   # fp32 accumulate, fp32 store
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I against an asymmetric W catches any transposed / permuted C-layout mistake."""
+    from hi3d_hip import ops
+    K = 320
+    A = bf(torch.eye(K))
+    W = bf(torch.arange(K * K, dtype=torch.float32).reshape(K, K) % 251 - 125.0)   # exactly representable
+    for tile in (128, 160):
+        out = ops.gemm(A.to(dev), W.to(dev), M=K, N=K, K=K, out_fp32=True, tile_n=tile)
+        assert torch.equal(out.cpu(), W.float().T.contiguous())
+
+
+@pytest.mark.parametrize("M,Nh,K", [(200, 320, 320), (130, 1280, 320), (64, 2560, 640)])
+def test_gemm_geglu(dev, M, Nh, K):
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_geglu
+    A = bf(rnd((M, K), 1))
+    W = bf(rnd((2 * Nh, K), 2, K ** -0.5)).float()
+    b = rnd((2 * Nh,), 3)
+    y = A.float() @ W.T + b
+    ref = y[:, :Nh] * F.gelu(y[:, Nh:])
+    Wp, bp = pack_geglu(W, b)
+    out = ops.gemm(A.to(dev), Wp.to(dev), M=M, N=2 * Nh, K=K, bias=bp.to(dev), geglu=True)
+    assert out.shape == (M, Nh)
+    assert relerr(out, ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
+                                                         (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
+                                                         (2, 9, 9, 64, 64, 2, 0)])
+def test_conv3x3(dev, Fr, H, W_, Cin, Cout, stride, up):
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3
+    x = bf(rnd((Fr, Cin, H, W_), 1))
+    w = bf(rnd((Cout, Cin, 3, 3), 2, (9 * Cin) ** -0.5)).float()
+    b = rnd((Cout,), 3)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin)
+    out = ops.gemm(xt.to(dev), pack_conv3x3(w, Cin).to(dev), M=Fr * Ho * Wo, N=Cout, K=9 * Cin, bias=b.to(dev),
+                   conv3x3=dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, up2x=up))
+    got = out.float().cpu().reshape(Fr, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert relerr(got, ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("B,T,HW,C", [(2, 4, 30, 64), (1, 16, 16, 320), (2, 1, 8, 64)])
+def test_conv_temporal(dev, B, T, HW, C):
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_convt3
+    x = bf(rnd((B, C, T, HW, 1), 1))
+    w = bf(rnd((C, C, 3, 1, 1), 2, (3 * C) ** -0.5)).float()
+    b = rnd((C,), 3)
+    ref = F.conv3d(x.float(), w, b, padding=(1, 0, 0))                    # b c t hw 1
+    xt = x.squeeze(-1).permute(0, 2, 3, 1).contiguous().reshape(-1, C)   # (b t hw) c
+    out = ops.gemm(xt.to(dev), pack_convt3(w).to(dev), M=B * T * HW, N=C, K=3 * C, bias=b.to(dev),
+                   convt3=dict(T=T, HW=HW, Cin=C))
+    got = out.float().cpu().reshape(B, T, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)
+    assert relerr(got, ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 2, 16), (1, 1, 4), (1, 3, 129)])
+def test_attention_d64(dev, B, H, S):
+    from hi3d_hip import ops
+    C = H * 64
+    qkv = bf(rnd((B * S, 3 * C), 1))
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * S, C)
+    out = ops.self_attention_fused_qkv(qkv.to(dev), B, S, H)
+    assert relerr(out, ref) < 2e-2     # P is rounded to bf16 before PV
+
+
+def test_attention_d64_online_softmax_rescale(dev):
+    """Force the running-max rescale: one key in a late tile dominates every query."""
+    from hi3d_hip import ops
+    B, H, S = 1, 1, 512
+    qkv = bf(rnd((S, 192), 3, 0.5)).float()
+    qkv[:, 0:64] = qkv[:, 0:64].abs()
+    qkv[300, 64:128] = 6.0      # key 300 (5th tile) dominates: q.k ~ 6*sum|q|
+    qkv = bf(qkv)
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(64, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, 64)
+    out = ops.self_attention_fused_qkv(qkv.to(dev), B, S, H)
+    assert relerr(out, ref) < 2e-2
+
+
+@pytest.mark.parametrize("B,T,S,H", [(2, 16, 50, 2), (1, 4, 33, 1), (1, 32, 20, 3), (2, 8, 16, 5), (1, 13, 9, 1)])
+def test_attention_temporal(dev, B, T, S, H):
+    from hi3d_hip import ops
+    C = H * 64
+    qkv = bf(rnd((B * T * S, 3 * C), 1))
+    # (b t s) (h d) -> (b s) h t d
+    q, k, v = [t.float().reshape(B, T, S, H, 64).permute(0, 2, 3, 1, 4).reshape(B * S, H, T, 64)
+               for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v)                     # (b s) h t d
+    ref = ref.reshape(B, S, H, T, 64).permute(0, 3, 1, 2, 4).reshape(B * T * S, C)
+    out = ops.attention_temporal_fused_qkv(qkv.to(dev), B, T, S, H)
+    assert relerr(out, ref) < 2e-2
+
+
+@pytest.mark.parametrize("inst,P,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 100, 64, False, 1e-6),
+                                               (2, 700, 960, True, 1e-5), (1, 64, 2560, True, 1e-5),
+                                               (2, 4 * 64, 1280, True, 1e-5), (1, 1030, 128, True, 1e-6)])
+def test_groupnorm_silu(dev, inst, P, C, silu, eps):
+    from hi3d_hip import ops
+    x = bf(rnd((inst, P, C), 1) * 2.0 + 0.7)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    xr = x.float().permute(0, 2, 1)                      # inst C P
+    ref = F.group_norm(xr, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1)
+    out = ops.groupnorm_silu(x.reshape(-1, C).to(dev), g.to(dev), b.to(dev), inst, P, C, eps, silu)
+    assert relerr(out.reshape(inst, P, C), ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("R,C,rpg", [(100, 320, 0), (37, 640, 5), (64, 1280, 64), (10, 64, 3)])
+def test_layernorm(dev, R, C, rpg):
+    from hi3d_hip import ops
+    x = bf(rnd((R, C), 1) * 1.5 + 0.3)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    if rpg:
+        G = (R + rpg - 1) // rpg
+        av = rnd((G, C), 4)
+        s = x.float() + av[torch.arange(R) // rpg]
+        so = torch.empty((R, C), device=dev, dtype=torch.bfloat16)
+        out = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), R, C, 1e-5, addvec=av.to(dev), rows_per_group=rpg, sum_out=so)
+        assert relerr(so, s) < 5e-3
+    else:
+        s = x.float()
+        out = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), R, C, 1e-5)
+    ref = F.layer_norm(s, (C,), g, b, 1e-5)
+    assert relerr(out, ref) < BF16_TOL
+
+
+def test_misc_kernels(dev):
+    from hi3d_hip import ops
+    # concat
+    a, b = bf(rnd((50, 64), 1)), bf(rnd((50, 128), 2))
+    out = ops.concat_channels(a.to(dev), b.to(dev), 50, 64, 128)
+    assert torch.equal(out.cpu(), torch.cat([a, b], 1))
+    # timestep embedding (reference formula: util.py:207-231)
+    t = torch.tensor([0.0, 1.0, 0.25 * math.log(700.0), 15.0, -1.3])
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ref = torch.cat([torch.cos(t[:, None] * freqs), torch.sin(t[:, None] * freqs)], -1)
+    got = ops.timestep_embedding(t.to(dev), 320)
+    assert (got.cpu() - ref).abs().max() < 2e-5
+    # silu
+    x = rnd((1000,), 3) * 3
+    assert relerr(ops.silu_to_bf16(x.to(dev)), F.silu(x)) < 5e-3
+    # layout converters
+    x = rnd((3, 5, 4, 6), 4)
+    tok = ops.nchw_to_tokens(x.to(dev), 8)
+    ref = torch.zeros(3, 24, 8)
+    ref[:, :, :5] = bf(x).float().reshape(3, 5, 24).permute(0, 2, 1)
+    assert torch.equal(tok.float().cpu().reshape(3, 24, 8), ref)
+    back = ops.tokens_to_nchw(tok, 3, 5, 4, 6, 8)
+    assert torch.equal(back.cpu(), bf(x).float())
+
+
+def test_cfg_prepare_and_sampler_step(dev):
+    """Closed forms of denoiser_scaling.py:51-59, guiders.py:78-86, sampling.py:93-107."""
+    from hi3d_hip import ops
+    T, H, W, Cc, Cp = 4, 6, 5, 13, 64
+    x = rnd((T, 4, H, W), 1) * 30
+    cu, cc = torch.zeros(T, Cc, H, W), rnd((T, Cc, H, W), 2)
+    sigma, sigma_next = 12.5, 7.25
+    c_in = 1 / math.sqrt(sigma ** 2 + 1)
+    out = ops.cfg_prepare(x.to(dev), cu.to(dev), cc.to(dev), Cp, sigma).float().cpu().reshape(2, T, H * W, Cp)
+    ref = torch.zeros(2, T, H * W, Cp)
+    ref[:, :, :, :4] = bf(x * c_in).float().reshape(T, 4, H * W).permute(0, 2, 1)
+    ref[1, :, :, 4:4 + Cc] = bf(cc).float().reshape(T, Cc, H * W).permute(0, 2, 1)
+    assert torch.equal(out, ref)
+    net = rnd((2, T, H * W, 4), 3)
+    scale = torch.linspace(1.0, 2.5, T)
+    c_skip, c_out = 1 / (sigma ** 2 + 1), -sigma / math.sqrt(sigma ** 2 + 1)
+    n_nchw = net.reshape(2, T, H, W, 4).permute(0, 1, 4, 2, 3)
+    du, dc = n_nchw[0] * c_out + x * c_skip, n_nchw[1] * c_out + x * c_skip
+    d = du + scale[:, None, None, None] * (dc - du)
+    ref_x = x + (sigma_next - sigma) * (x - d) / sigma
+    xs = x.clone().to(dev)
+    ops.sampler_step(xs, net.to(dev), scale.to(dev), 4, sigma, sigma_next)
+    assert relerr(xs, ref_x) < 1e-5
+
+
+def test_errors_are_loud(dev):
+    from hi3d_hip import ops
+    from hi3d_hip.lib import Hi3dError
+    A = torch.zeros((64, 72), device=dev, dtype=torch.bfloat16)
+    W = torch.zeros((64, 72), device=dev, dtype=torch.bfloat16)
+    with pytest.raises(Hi3dError, match="multiple of 64"):
+        ops.gemm(A, W, M=64, N=64, K=72)
+    with pytest.raises(Hi3dError, match="CPU tensor"):
+        ops.gemm(A.cpu(), W, M=64, N=64, K=64)
