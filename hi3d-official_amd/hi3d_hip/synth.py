@@ -1,0 +1,69 @@
+"""Deterministic synthetic weights and conditioning for the Hi3D hot path.
+
+There are no checkpoints in the reference tree (README.md:35-39 are download links)
+and a freshly constructed VideoUNet outputs exactly 0 because of its zero-initialised
+layers (openaimodel.py:296-304, attention.py:693-699, video_model.py:436-440;
+SURVEY.md section 0.6).  Parity tests and the benchmark therefore use weights drawn
+here: every tensor is generated from a seed derived from ITS OWN KEY, so the values do
+not depend on parameter registration order -- the reference modules (in the build
+container) and this package's modules (anywhere) get bit-identical tensors.
+"""
+import zlib
+
+import torch
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) * 2654435761 + seed * 1000003) & 0x7FFFFFFFFFFF)
+    return g
+
+
+def synth_tensor(key: str, shape, seed: int = 1) -> torch.Tensor:
+    """fp32 CPU tensor for state_dict entry `key`."""
+    shape = tuple(shape)
+    g = _gen(key, seed)
+    r = torch.randn(shape, generator=g, dtype=torch.float32)
+    if key.endswith("mix_factor"):
+        return 0.5 + 0.75 * r                      # alpha = sigmoid(.) spread over (0.2, 0.9)
+    if len(shape) >= 2:                            # conv / linear weight
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        return r * (fan_in ** -0.5)
+    if key.endswith("weight"):                     # norm gain
+        return 1.0 + 0.1 * r
+    return 0.05 * r                                # biases
+
+
+def synth_state_dict(shapes: dict, seed: int = 1) -> dict:
+    """shapes: {key: shape} -> {key: fp32 tensor}"""
+    return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
+
+
+def fill_module_(module: torch.nn.Module, seed: int = 1, prefix: str = "") -> None:
+    """Overwrite every parameter/buffer of `module` in place (keys = state_dict keys)."""
+    sd = module.state_dict()
+    new = {k: synth_tensor(prefix + k, v.shape, seed).to(v.dtype) for k, v in sd.items()
+           if v.dtype.is_floating_point}
+    module.load_state_dict(new, strict=False)
+
+
+def synth_conditioning(T: int, h: int, w: int, stage: int = 1, seed: int = 0, context_dim: int = 1024,
+                       adm_in: int = None):
+    """Synthetic (c, uc) with the shapes the Hi3D conditioner emits:
+    crossattn [1,1,1024] (uc: zeros), vector [1,adm] (same in uc), concat [T,Cc,h,w]
+    (uc: zeros); Cc = 4 (stage 1) or 9+4 (stage 2: depth ~U[0,1] then latent)."""
+    g = torch.Generator().manual_seed(seed)
+    adm = adm_in if adm_in is not None else (768 if stage == 1 else 512)
+    cc = 4 if stage == 1 else 13
+    concat = torch.randn((T, cc, h, w), generator=g)
+    if stage == 2:
+        concat[:, :9] = torch.rand((T, 9, h, w), generator=g)
+    c = {"crossattn": torch.randn((1, 1, context_dim), generator=g),
+         "vector": torch.randn((1, adm), generator=g),
+         "concat": concat}
+    uc = {"crossattn": torch.zeros_like(c["crossattn"]), "vector": c["vector"].clone(),
+          "concat": torch.zeros_like(concat)}
+    x = torch.randn((T, 4, h, w), generator=g)
+    return x, c, uc

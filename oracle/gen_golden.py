@@ -1,0 +1,183 @@
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.pt by running the REFERENCE classes.
+
+Runs only in the build container (needs /root/reference; see oracle/ref_import.py for the
+four inert stand-in modules).  Each fixture stores the seeded inputs, the config, the
+weight seed (weights are re-derived per key by hi3d_hip.synth, never stored) and the
+reference's fp32 CPU output.  Deviations from the shipped YAMLs, all numerically neutral
+(SURVEY.md 8c): attention type `softmax` (SDPA) instead of xformers, VAE attn `vanilla`,
+sampler device cpu, use_checkpoint False, zero-initialised parameters re-drawn.
+
+usage:  python oracle/gen_golden.py [--only NAME] [--full]
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "hi3d-official_amd", "hi3d_hip"))  # synth only (no package import: name clash with reference `sgm`)
+import ref_import  # noqa: E402
+import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+UNET_PREFIX = "model.diffusion_model."
+VAE_PREFIX = "first_stage_model."
+
+
+def unet_cfg(stage, mc=320):
+    return dict(in_channels=8 if stage == 1 else 17, model_channels=mc, out_channels=4, num_res_blocks=2,
+                attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_head_channels=64,
+                use_linear_in_transformer=True, transformer_depth=1, context_dim=1024,
+                spatial_transformer_attn_type="softmax", extra_ff_mix_layer=True, use_spatial_context=True,
+                merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1], num_classes="sequential",
+                adm_in_channels=768 if stage == 1 else 512, use_checkpoint=False)
+
+
+def vae_ddconfig(ch=128):
+    return dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3,
+                ch=ch, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def shapes_digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(f"{k}:{tuple(sd[k].shape)};".encode())
+    return h.hexdigest()
+
+
+def build_unet(cfg, seed):
+    VideoUNet = ref_import.ref("sgm.modules.diffusionmodules.video_model.VideoUNet")
+    m = VideoUNet(**cfg).eval()
+    synth.fill_module_(m, seed, prefix=UNET_PREFIX)
+    return m
+
+
+def unet_inputs(cfg, T, hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = 2 * T
+    return dict(
+        x=torch.randn((B, cfg["in_channels"], hw, hw), generator=g),
+        timesteps=0.25 * torch.log(torch.rand((B,), generator=g) * 50 + 0.01),
+        context=torch.randn((2, 1, cfg["context_dim"]), generator=g),
+        y=torch.randn((2, cfg["adm_in_channels"]), generator=g),
+        image_only_indicator=torch.zeros(2, T),
+    )
+
+
+def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None):
+    t0 = time.time()
+    m = build_unet(cfg, wseed)
+    inp = unet_inputs(cfg, T, hw, iseed)
+    if ioi is not None:
+        inp["image_only_indicator"] = ioi
+    with torch.no_grad():
+        out = m(inp["x"], inp["timesteps"], context=inp["context"], y=inp["y"], time_context=None,
+                num_video_frames=T, image_only_indicator=inp["image_only_indicator"])
+    sd = m.state_dict()
+    fx = dict(kind="unet", cfg=cfg, T=T, weight_seed=wseed, key_prefix=UNET_PREFIX, inputs=inp, output=out,
+              n_tensors=len(sd), shapes_sha256=shapes_digest(sd), shapes={k: tuple(v.shape) for k, v in sd.items()},
+              probe={k: sd[k].flatten()[:4].clone() for k in list(sd)[:3]})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} std {out.std():.4f}  ({time.time() - t0:.1f}s)")
+
+
+def gen_sampler(name, cfg, T, hw, steps, max_scale, stage, wseed=1, iseed=0):
+    t0 = time.time()
+    unet = build_unet(cfg, wseed)
+    Wrapper = ref_import.ref("sgm.modules.diffusionmodules.wrappers.OpenAIWrapper")
+    Denoiser = ref_import.ref("sgm.modules.diffusionmodules.denoiser.Denoiser")
+    Sampler = ref_import.ref("sgm.modules.diffusionmodules.sampling.EulerEDMSampler")
+    model = Wrapper(unet)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = Sampler(
+        num_steps=steps, verbose=False, device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                               "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": max_scale, "min_scale": 1.0}})
+    x0, c, uc = synth.synth_conditioning(T, hw, hw, stage=stage, seed=iseed, adm_in=cfg["adm_in_channels"])
+    extra = dict(image_only_indicator=torch.zeros(2, T), num_video_frames=T)
+    traj = []
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+
+    with torch.no_grad():
+        # same loop as EDMSampler.__call__, unrolled through step_call (the v02 entry point)
+        # so the per-step states can be recorded
+        x, s_in, sigmas, num_sigmas, cond, ucond = sampler.prepare_sampling_loop(x0.clone(), c, uc, steps)
+        for i in sampler.get_sigma_gen(num_sigmas):
+            x = sampler.step_call(denoiser, x, i, s_in, sigmas, num_sigmas, cond, ucond)
+            traj.append(x.clone())
+        whole = sampler(denoiser, x0.clone(), cond=c, uc=uc)
+    assert torch.equal(whole, x)
+    fx = dict(kind="sampler", cfg=cfg, T=T, steps=steps, max_scale=max_scale, stage=stage, weight_seed=wseed,
+              key_prefix=UNET_PREFIX, x0=x0, c=c, uc=uc, sigmas=sigmas, traj=torch.stack(traj), output=x,
+              shapes={k: tuple(v.shape) for k, v in unet.state_dict().items()})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: final absmax {x.abs().max():.4f} std {x.std():.4f} ({time.time() - t0:.1f}s)")
+
+
+def gen_vae(name, ch, n, hw, wseed=1, iseed=0):
+    t0 = time.time()
+    AE = ref_import.ref("sgm.models.autoencoder.AutoencoderKL")
+    dd = vae_ddconfig(ch)
+    ae = AE(embed_dim=4, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}).eval()
+    synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
+    g = torch.Generator().manual_seed(iseed)
+    z = torch.randn((n, 4, hw, hw), generator=g)
+    with torch.no_grad():
+        out = ae.decode(z / 0.18215)      # decode_first_stage does z / scale_factor first (diffusion.py:119)
+    sd = ae.state_dict()
+    fx = dict(kind="vae_decode", ddconfig=dd, weight_seed=wseed, key_prefix=VAE_PREFIX, z=z, output=out,
+              shapes={k: tuple(v.shape) for k, v in sd.items()}, shapes_sha256=shapes_digest(sd))
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
+
+
+def gen_schedule(name):
+    Disc = ref_import.ref("sgm.modules.diffusionmodules.discretizer.EDMDiscretization")
+    Scal = ref_import.ref("sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise")
+    d = Disc(sigma_max=700.0)
+    sig = {n: d(n, device="cpu") for n in (5, 25)}
+    s = torch.tensor([700.0, 134.85, 15.59, 0.67815, 0.002])
+    fx = dict(kind="schedule", sigmas=sig, scaling_in=s, scaling_out=[t.clone() for t in Scal()(s)])
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(name, sig[5])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--full", action="store_true", help="also the full-size stage-1 UNet forward (~3 min, 8 cores)")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    jobs = {
+        "schedule": lambda: gen_schedule("schedule"),
+        "unet_tiny_s1": lambda: gen_unet("unet_tiny_s1", unet_cfg(1, 64), T=4, hw=16),
+        "unet_tiny_s2_ioi": lambda: gen_unet("unet_tiny_s2_ioi", unet_cfg(2, 64), T=3, hw=8, iseed=3,
+                                              ioi=torch.tensor([[0., 1., 0.], [0., 0., 1.]])),
+        "sampler_tiny_s1": lambda: gen_sampler("sampler_tiny_s1", unet_cfg(1, 64), T=4, hw=16, steps=5,
+                                               max_scale=2.5, stage=1),
+        "sampler_tiny_s2": lambda: gen_sampler("sampler_tiny_s2", unet_cfg(2, 64), T=4, hw=8, steps=4,
+                                               max_scale=2.0, stage=2, iseed=5),
+        "vae_tiny": lambda: gen_vae("vae_tiny", 32, 2, 8),
+        "vae_full_lat8": lambda: gen_vae("vae_full_lat8", 128, 1, 8, iseed=2),
+        "unet_s1_lat16": lambda: gen_unet("unet_s1_lat16", unet_cfg(1), T=4, hw=16, iseed=1),
+        "unet_s2_lat16": lambda: gen_unet("unet_s2_lat16", unet_cfg(2), T=4, hw=16, iseed=2),
+    }
+    if a.full:
+        jobs["unet_s1_full"] = lambda: gen_unet("unet_s1_full", unet_cfg(1), T=16, hw=64, iseed=7)
+    for k, fn in jobs.items():
+        if a.only is None or a.only == k:
+            fn()
+
+
+if __name__ == "__main__":
+    main()

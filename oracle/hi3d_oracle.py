@@ -1,0 +1,314 @@
+"""TEST INFRASTRUCTURE -- CPU fp32 oracle for the Hi3D denoising hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+module; the product path (hi3d-official_amd/) never does and has no CPU fallback.
+
+A functional restatement (plain torch fp32 on CPU, NCHW like the reference) of what the
+reference's nn.Module tree computes on this path.  Weights come in as a flat
+`state_dict`-style mapping using the REFERENCE'S key names, so the same checkpoint /
+synthetic tensors drive the reference, this oracle and the HIP path.
+
+Pinned (tests/test_oracle_cpu.py) against golden vectors produced by running the
+reference's own classes in the build container (oracle/gen_golden.py ->
+tests/golden/*.pt).  The reference itself has no golden vectors or tests for this path
+(SURVEY.md section 4), so those generated fixtures are the pin.
+
+All citations are relative to /root/reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# leaf pieces
+# --------------------------------------------------------------------------------------
+def sinusoid(t, dim, max_period=10000.0):
+    """cos || sin embedding -- sgm/modules/diffusionmodules/util.py:207-231."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    args = t.float()[:, None] * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _gn(sd, p, x, eps):
+    return F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def _mlp2(sd, p, x):
+    """Linear-SiLU-Linear stored as p.0 / p.2 (video_model.py:151-182; video_attention.py:220-224)."""
+    return _lin(sd, p + ".2", F.silu(_lin(sd, p + ".0", x)))
+
+
+def _mha(q, k, v, heads):
+    """softmax(q k^T / sqrt(d)) v with heads packed as '(h d)' -- attention.py:281-344."""
+    b, n, c = q.shape
+    d = c // heads
+    split = lambda t: t.reshape(b, t.shape[1], heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(split(q), split(k), split(v))
+    return o.transpose(1, 2).reshape(b, n, c)
+
+
+def _attn(sd, p, x, ctx, heads):
+    """CrossAttention.forward (attention.py:281-344): context=None means self-attention."""
+    src = x if ctx is None else ctx
+    o = _mha(F.linear(x, sd[p + ".to_q.weight"]), F.linear(src, sd[p + ".to_k.weight"]),
+             F.linear(src, sd[p + ".to_v.weight"]), heads)
+    return _lin(sd, p + ".to_out.0", o)
+
+
+def _geglu_ff(sd, p, x):
+    """FeedForward with GEGLU (attention.py:87-113): net.0.proj -> a * gelu(g) -> net.2."""
+    a, g = _lin(sd, p + ".net.0.proj", x).chunk(2, dim=-1)
+    return _lin(sd, p + ".net.2", a * F.gelu(g))
+
+
+def _alpha(sd, p, image_only_indicator):
+    """AlphaBlender 'learned_with_images' (util.py:341-357): 1 where the frame is
+    image-only, sigmoid(mix_factor) elsewhere.  Returns [b, t]."""
+    a = torch.sigmoid(sd[p + ".mix_factor"]).reshape(1, 1)
+    return torch.where(image_only_indicator.bool(), torch.ones(1, 1), a)
+
+
+# --------------------------------------------------------------------------------------
+# UNet blocks
+# --------------------------------------------------------------------------------------
+def resblock(sd, p, x, emb, dims):
+    """ResBlock._forward, non-updown / non-scale-shift branch (openaimodel.py:328-354).
+    dims=2: x [N,C,H,W], emb [N,E].  dims=3 (time_stack, exchange_temb_dims):
+    x [b,C,t,H,W], emb [b,t,E] and the embedding lands on [b,C,t,1,1]."""
+    conv = F.conv2d if dims == 2 else F.conv3d
+    pad = 1 if dims == 2 else (1, 0, 0)
+    h = conv(F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5)), sd[p + ".in_layers.2.weight"],
+             sd[p + ".in_layers.2.bias"], padding=pad)
+    e = _lin(sd, p + ".emb_layers.1", F.silu(emb))
+    if dims == 2:
+        e = e[:, :, None, None]
+    else:
+        e = e.transpose(1, 2)[:, :, :, None, None]          # b t c -> b c t 1 1
+    h = h + e
+    h = conv(F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5)), sd[p + ".out_layers.3.weight"],
+             sd[p + ".out_layers.3.bias"], padding=pad)
+    if (p + ".skip_connection.weight") in sd:                # 1x1 conv when channels change (:314)
+        x = conv(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
+    return x + h
+
+
+def video_resblock(sd, p, x, emb, T, ioi):
+    """VideoResBlock.forward (video_model.py:62-81): spatial ResBlock, then the temporal
+    ResBlock on 'b c t h w', blended per frame by AlphaBlender('b t -> b 1 t 1 1')."""
+    x = resblock(sd, p, x, emb, 2)
+    n, c, hh, ww = x.shape
+    b = n // T
+    x5 = x.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)
+    xt = resblock(sd, p + ".time_stack", x5, emb.reshape(b, T, -1), 3)
+    a = _alpha(sd, p + ".time_mixer", ioi)[:, None, :, None, None]
+    out = a * x5 + (1.0 - a) * xt
+    return out.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+
+
+def spatial_video_transformer(sd, p, x, ctx, T, ioi, heads, depth=1):
+    """SpatialVideoTransformer.forward (video_attention.py:230-301) with
+    use_linear=True, use_spatial_context=True, ff_in=True (configs/inference-v01.yaml:39-46)."""
+    n, c, hh, ww = x.shape
+    b, s = n // T, hh * ww
+    x_in = x
+    # time context = context of each clip's first frame, one copy per pixel (:249-253)
+    tctx = ctx[::T].repeat_interleave(s, dim=0)
+    h = _gn(sd, p + ".norm", x, 1e-6).reshape(n, c, s).transpose(1, 2)      # b (h w) c
+    h = _lin(sd, p + ".proj_in", h)
+    # frame-position embedding (:266-276) -- depends on T only
+    pos = _mlp2(sd, p + ".time_pos_embed", sinusoid(torch.arange(T).repeat(b), c))[:, None, :]
+    a = _alpha(sd, p + ".time_mixer", ioi).reshape(n, 1, 1)                  # 'b t -> (b t) 1 1'
+    for d in range(depth):
+        sp, tp = f"{p}.transformer_blocks.{d}", f"{p}.time_stack.{d}"
+        # BasicTransformerBlock._forward (attention.py:551-572)
+        h = h + _attn(sd, sp + ".attn1", _ln(sd, sp + ".norm1", h), None, heads)
+        h = h + _attn(sd, sp + ".attn2", _ln(sd, sp + ".norm2", h), ctx, heads)
+        h = h + _geglu_ff(sd, sp + ".ff", _ln(sd, sp + ".norm3", h))
+        # VideoTransformerBlock._forward (video_attention.py:109-140) on '(b s) t c'
+        m = (h + pos).reshape(b, T, s, c).permute(0, 2, 1, 3).reshape(b * s, T, c)
+        m = m + _geglu_ff(sd, tp + ".ff_in", _ln(sd, tp + ".norm_in", m))
+        m = m + _attn(sd, tp + ".attn1", _ln(sd, tp + ".norm1", m), None, heads)
+        m = m + _attn(sd, tp + ".attn2", _ln(sd, tp + ".norm2", m), tctx, heads)
+        m = m + _geglu_ff(sd, tp + ".ff", _ln(sd, tp + ".norm3", m))
+        m = m.reshape(b, s, T, c).permute(0, 2, 1, 3).reshape(n, s, c)
+        h = a * h + (1.0 - a) * m                                            # (:290-294)
+    h = _lin(sd, p + ".proj_out", h)
+    return h.transpose(1, 2).reshape(n, c, hh, ww) + x_in
+
+
+def unet_layout(cfg):
+    """Block plan of VideoUNet.__init__ (video_model.py:186-440) for resblock_updown=False:
+    returns (input_blocks, middle, output_blocks) as lists of layer tags per block."""
+    mc, mult, nres = cfg["model_channels"], list(cfg["channel_mult"]), cfg["num_res_blocks"]
+    att = set(cfg["attention_resolutions"])
+    inp, chans, ch, ds = [[("conv_in",)]], [mc], mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            layers = [("res", ch, m * mc)]
+            ch = m * mc
+            if ds in att:
+                layers.append(("attn", ch))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inp.append([("down", ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", ch, ch), ("attn", ch), ("res", ch, ch)]
+    outp = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, mc * m)]
+            ch = mc * m
+            if ds in att:
+                layers.append(("attn", ch))
+            if level and i == nres:
+                layers.append(("up", ch))
+                ds //= 2
+            outp.append(layers)
+    return inp, mid, outp
+
+
+def video_unet(sd, cfg, x, timesteps, context, y, T, ioi, prefix=""):
+    """VideoUNet.forward (video_model.py:442-501).  x [b*T, Cin, H, W]; timesteps [b*T];
+    context [b or b*T, 1, ctx]; y [b or b*T, adm]; ioi [b, T]."""
+    P = prefix
+    nheads = lambda ch: ch // cfg["num_head_channels"]
+    if y.shape[0] != x.shape[0]:                     # "fast implementation" repeat (:459-465)
+        y = y.repeat_interleave(T, dim=0)
+    if context.shape[0] != x.shape[0]:
+        context = context.repeat_interleave(T, dim=0)
+    emb = _mlp2(sd, P + "time_embed", sinusoid(timesteps, cfg["model_channels"]))
+    emb = emb + _mlp2(sd, P + "label_emb.0", y)
+    inp, mid, outp = unet_layout(cfg)
+
+    def run(h, layers, base):
+        for j, L in enumerate(layers):
+            p = f"{base}.{j}"
+            if L[0] == "conv_in":
+                h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+            elif L[0] == "res":
+                h = video_resblock(sd, p, h, emb, T, ioi)
+            elif L[0] == "attn":
+                h = spatial_video_transformer(sd, p, h, context, T, ioi, nheads(L[1]))
+            elif L[0] == "down":                     # Downsample, stride-2 conv (openaimodel.py:192-199)
+                h = F.conv2d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)
+            elif L[0] == "up":                       # Upsample: nearest 2x + conv (openaimodel.py:154-156)
+                h = F.conv2d(F.interpolate(h, scale_factor=2, mode="nearest"),
+                             sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
+        return h
+
+    h, hs = x, []
+    for i, layers in enumerate(inp):
+        h = run(h, layers, f"{P}input_blocks.{i}")
+        hs.append(h)
+    h = run(h, mid, P + "middle_block")
+    for i, layers in enumerate(outp):
+        h = run(torch.cat([h, hs.pop()], dim=1), layers, f"{P}output_blocks.{i}")
+    h = F.silu(_gn(sd, P + "out.0", h, 1e-5))
+    return F.conv2d(h, sd[P + "out.2.weight"], sd[P + "out.2.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------------------
+# sampling control
+# --------------------------------------------------------------------------------------
+def edm_sigmas(n, sigma_min=0.002, sigma_max=700.0, rho=7.0):
+    """EDMDiscretization.get_sigmas + append_zero (discretizer.py:17-39)."""
+    ramp = torch.linspace(0, 1, n)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return torch.cat([(hi + ramp * (lo - hi)) ** rho, torch.zeros(1)])
+
+
+def denoise_cfg(sd, cfg, x, sigma, c, uc, T, scale, prefix="model.diffusion_model."):
+    """One guided denoiser evaluation for a scalar sigma:
+    guiders.py:88-99 (batch doubling uc||c) -> denoiser.py:23-39 with
+    VScalingWithEDMcNoise (denoiser_scaling.py:51-59) -> wrappers.py:23-34 (cat concat)
+    -> VideoUNet -> guiders.py:78-86 (per-frame linear CFG scale)."""
+    xx = torch.cat([x, x])
+    s = torch.full((xx.shape[0],), float(sigma))
+    c_skip, c_out = 1.0 / (s ** 2 + 1.0), -s / (s ** 2 + 1.0) ** 0.5
+    c_in, c_noise = 1.0 / (s ** 2 + 1.0) ** 0.5, 0.25 * s.log()
+    bc = lambda v: v[:, None, None, None]
+    net_in = torch.cat([xx * bc(c_in), torch.cat([uc["concat"], c["concat"]])], dim=1)
+    ioi = torch.zeros(2, T)
+    out = video_unet(sd, cfg, net_in, c_noise, torch.cat([uc["crossattn"], c["crossattn"]]),
+                     torch.cat([uc["vector"], c["vector"]]), T, ioi, prefix)
+    den = out * bc(c_out) + xx * bc(c_skip)
+    d_u, d_c = den.chunk(2)
+    return d_u + scale.reshape(-1, 1, 1, 1) * (d_c - d_u)
+
+
+def euler_edm_sample(sd, cfg, x, c, uc, T, num_steps, max_scale, min_scale=1.0, sigma_max=700.0,
+                     prefix="model.diffusion_model.", return_all=False):
+    """EulerEDMSampler.__call__ with s_churn=0 (sampling.py:41-52,93-147,228-232;
+    sampling_utils.py:34-35): x *= sqrt(1+s0^2); x += (s_{i+1}-s_i) * (x - D)/s_i."""
+    sig = edm_sigmas(num_steps, sigma_max=sigma_max)
+    scale = torch.linspace(min_scale, max_scale, T)
+    x = x * torch.sqrt(1.0 + sig[0] ** 2)
+    traj = []
+    for i in range(num_steps):
+        d = denoise_cfg(sd, cfg, x, sig[i], c, uc, T, scale, prefix)
+        x = x + (sig[i + 1] - sig[i]) * (x - d) / sig[i]
+        traj.append(x)
+    return (x, traj) if return_all else x
+
+
+# --------------------------------------------------------------------------------------
+# first stage (2-D AutoencoderKL decoder, the one the shipped configs wire)
+# --------------------------------------------------------------------------------------
+def _vae_resnet(sd, p, x):
+    """ResnetBlock.forward with temb=None (model.py:131-151); GroupNorm eps 1e-6 (:52-55)."""
+    h = F.conv2d(F.silu(_gn(sd, p + ".norm1", x, 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(_gn(sd, p + ".norm2", h, 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if (p + ".nin_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def _vae_attn(sd, p, x):
+    """AttnBlock (model.py:161-200): single head, d = C, 1x1-conv q/k/v/proj_out."""
+    b, c, hh, ww = x.shape
+    n = _gn(sd, p + ".norm", x, 1e-6)
+    q, k, v = [F.conv2d(n, sd[f"{p}.{t}.weight"], sd[f"{p}.{t}.bias"]).reshape(b, c, -1).transpose(1, 2)
+               for t in ("q", "k", "v")]
+    o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    o = o.transpose(1, 2).reshape(b, c, hh, ww)
+    return x + F.conv2d(o, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+
+
+def vae_decode(sd, dd, z, scale_factor=0.18215, prefix="first_stage_model."):
+    """DiffusionEngine.decode_first_stage (models/diffusion.py:117-135) ->
+    AutoencodingEngineLegacy.decode (models/autoencoder.py:490-505: post_quant_conv) ->
+    Decoder.forward (model.py:715-748).  dd = ddconfig dict."""
+    P = prefix
+    z = z / scale_factor
+    z = F.conv2d(z, sd[P + "post_quant_conv.weight"], sd[P + "post_quant_conv.bias"])
+    D = P + "decoder."
+    h = F.conv2d(z, sd[D + "conv_in.weight"], sd[D + "conv_in.bias"], padding=1)
+    h = _vae_resnet(sd, D + "mid.block_1", h)
+    h = _vae_attn(sd, D + "mid.attn_1", h)
+    h = _vae_resnet(sd, D + "mid.block_2", h)
+    nlev = len(dd["ch_mult"])
+    for lvl in reversed(range(nlev)):
+        for blk in range(dd["num_res_blocks"] + 1):
+            h = _vae_resnet(sd, f"{D}up.{lvl}.block.{blk}", h)
+        if lvl != 0:                                  # Upsample (model.py:58-71)
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"),
+                         sd[f"{D}up.{lvl}.upsample.conv.weight"], sd[f"{D}up.{lvl}.upsample.conv.bias"], padding=1)
+    h = F.silu(_gn(sd, D + "norm_out", h, 1e-6))
+    return F.conv2d(h, sd[D + "conv_out.weight"], sd[D + "conv_out.bias"], padding=1)

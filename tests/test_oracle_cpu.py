@@ -1,0 +1,91 @@
+"""Pin the CPU oracle (oracle/hi3d_oracle.py) against golden vectors produced by the
+reference's own classes (oracle/gen_golden.py).  fp32 vs fp32 on the same torch build:
+the only differences are summation order inside identical ATen kernels."""
+import glob
+import os
+
+import pytest
+import torch
+
+from hi3d_hip import synth
+from oracle import hi3d_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-4      # max-abs error / max-abs reference, fp32 restatement vs fp32 reference
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+
+
+def weights(fx):
+    return synth.synth_state_dict({fx["key_prefix"] + k: s for k, s in fx["shapes"].items()}, fx["weight_seed"])
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def test_schedule_and_scaling_known_answers():
+    fx = load("schedule")
+    for n, ref in fx["sigmas"].items():
+        assert torch.allclose(O.edm_sigmas(n), ref, rtol=1e-6, atol=0)
+    s5 = O.edm_sigmas(5)
+    # closed-form KATs: endpoints of the rho-schedule and the appended zero
+    assert abs(s5[0].item() - 700.0) < 1e-3 and abs(s5[4].item() - 0.002) < 1e-8 and s5[5].item() == 0.0
+    s = fx["scaling_in"]
+    c_skip, c_out, c_in, c_noise = fx["scaling_out"]
+    assert torch.allclose(c_skip + c_out ** 2, torch.ones_like(s), atol=1e-6)      # identities of VScaling
+    assert torch.allclose(c_in ** 2, c_skip, rtol=1e-6)
+    assert torch.allclose(c_noise, 0.25 * s.log())
+
+
+def test_synth_weights_are_reproducible():
+    fx = load("unet_tiny_s1")
+    sd = weights(fx)
+    for k, v in fx["probe"].items():
+        assert torch.equal(sd[fx["key_prefix"] + k].flatten()[:4], v), "torch CPU RNG differs from the fixture build"
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_s1", "unet_tiny_s2_ioi"])
+def test_unet_oracle_matches_reference(name):
+    fx = load(name)
+    i = fx["inputs"]
+    with torch.no_grad():
+        out = O.video_unet(weights(fx), fx["cfg"], i["x"], i["timesteps"], i["context"], i["y"], fx["T"],
+                           i["image_only_indicator"], prefix=fx["key_prefix"])
+    assert rel(out, fx["output"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["sampler_tiny_s1", "sampler_tiny_s2"])
+def test_sampler_oracle_matches_reference(name):
+    fx = load(name)
+    with torch.no_grad():
+        out, traj = O.euler_edm_sample(weights(fx), fx["cfg"], fx["x0"], fx["c"], fx["uc"], fx["T"], fx["steps"],
+                                       fx["max_scale"], prefix=fx["key_prefix"], return_all=True)
+    for k in range(fx["steps"]):
+        assert rel(traj[k], fx["traj"][k]) < TOL, f"step {k}"
+    assert rel(out, fx["output"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["vae_tiny", "vae_full_lat8"])
+def test_vae_decode_oracle_matches_reference(name):
+    fx = load(name)
+    with torch.no_grad():
+        out = O.vae_decode(weights(fx), fx["ddconfig"], fx["z"], prefix=fx["key_prefix"])
+    assert rel(out, fx["output"]) < TOL
+
+
+def test_cross_attention_single_token_identity():
+    """One context token => softmax == 1 => attn2(x) = to_out(to_v(ctx)) for every query
+    (SURVEY 0.7).  The HIP path relies on this exact elimination."""
+    g = torch.Generator().manual_seed(0)
+    C, ctxd = 128, 1024
+    sd = {"a.to_q.weight": torch.randn(C, C, generator=g), "a.to_k.weight": torch.randn(C, ctxd, generator=g),
+          "a.to_v.weight": torch.randn(C, ctxd, generator=g) * 0.03, "a.to_out.0.weight": torch.randn(C, C, generator=g) * 0.1,
+          "a.to_out.0.bias": torch.randn(C, generator=g)}
+    x, ctx = torch.randn(3, 50, C, generator=g), torch.randn(3, 1, ctxd, generator=g)
+    full = O._attn(sd, "a", x, ctx, heads=2)
+    vec = torch.nn.functional.linear(torch.nn.functional.linear(ctx, sd["a.to_v.weight"]), sd["a.to_out.0.weight"],
+                                     sd["a.to_out.0.bias"])
+    assert torch.allclose(full, vec.expand_as(full), rtol=1e-5, atol=1e-5)
