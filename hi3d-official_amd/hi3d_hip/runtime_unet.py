@@ -1,0 +1,335 @@
+"""Execution runtime of the Hi3D VideoUNet on MI355X.
+
+The nn.Module tree in sgm/modules/diffusionmodules/video_model.py only carries the
+reference's parameter names (state_dict compatibility).  This runtime is what runs:
+
+  * at load, every weight is re-laid-out once into the K-major bf16 image the gfx950
+    GEMM consumes (hi3d_hip.pack): conv OIHW -> [O][(ky,kx,I)], Conv3d (3,1,1) ->
+    [O][(kt,I)], to_q/k/v fused into one [3C][C] matrix, GEGLU rows interleaved,
+    all 44 `emb_layers` Linear layers stacked into ONE [sum(C)][4*mc] matrix;
+  * activations live in ONE layout for the whole network -- channels-last tokens
+    [(b t), h*w, C] in bf16 -- so none of the reference's permutes
+    (video_model.py:71-80, video_attention.py:114,137-139, attention.py:711,720)
+    exists here: the temporal ResBlock / temporal attention kernels index the frame
+    axis themselves;
+  * every elementwise tail (bias, timestep-embedding broadcast, residual adds,
+    AlphaBlender, GEGLU) is a GEMM epilogue; GroupNorm+SiLU and LayerNorm
+    (+frame-position embedding) are single fused passes;
+  * the single-token cross-attention (CLIP image embedding, [B,1,1024]) is eliminated
+    algebraically: softmax over one key == 1, so attn2(x) = to_out(to_v(ctx)) is a
+    per-frame vector added in the epilogue of the preceding GEMM (exact).
+    Those vectors and the frame-position embeddings depend only on the conditioning,
+    so they are cached across the 25 sampler steps.
+"""
+import torch
+
+from . import ops, pack
+
+
+def unet_layout(cfg):
+    """Walk VideoUNet's constructor logic (reference video_model.py:186-440,
+    resblock_updown=False) and return the per-block layer lists."""
+    mc, mult, nres = cfg["model_channels"], list(cfg["channel_mult"]), cfg["num_res_blocks"]
+    att = set(cfg["attention_resolutions"])
+    blocks_in, skip_ch, ch, ds = [[("conv_in",)]], [mc], mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            layers = [("res", ch, m * mc)]
+            ch = m * mc
+            if ds in att:
+                layers.append(("attn", ch))
+            blocks_in.append(layers)
+            skip_ch.append(ch)
+        if level != len(mult) - 1:
+            blocks_in.append([("down", ch)])
+            skip_ch.append(ch)
+            ds *= 2
+    middle = [("res", ch, ch), ("attn", ch), ("res", ch, ch)]
+    blocks_out = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            ich = skip_ch.pop()
+            layers = [("res", ch + ich, mc * m)]
+            ch = mc * m
+            if ds in att:
+                layers.append(("attn", ch))
+            if level and i == nres:
+                layers.append(("up", ch))
+                ds //= 2
+            blocks_out.append(layers)
+    return blocks_in, middle, blocks_out
+
+
+CIN_PAD = 64   # the 8 / 17 input channels are zero-padded to one 64-wide K chunk
+
+
+class UNetRuntime:
+    def __init__(self, state_dict, cfg, device, prefix=""):
+        self.cfg = dict(cfg)
+        self.dev = torch.device(device)
+        self.mc = cfg["model_channels"]
+        self.hd = cfg["num_head_channels"]
+        if self.hd != 64:
+            raise ops._l.Hi3dError("UNetRuntime: only num_head_channels == 64 has a gfx950 attention kernel")
+        if cfg.get("transformer_depth", 1) != 1:
+            raise ops._l.Hi3dError("UNetRuntime: transformer_depth != 1 not supported")
+        if cfg["in_channels"] > CIN_PAD:
+            raise ops._l.Hi3dError("UNetRuntime: in_channels > 64 not supported")
+        self.layout = unet_layout(cfg)
+        self._cond_cache = None
+        self._pos_cache = {}
+        self._pack(state_dict, prefix)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, sd, P):
+        dev = self.dev
+        g = lambda k: sd[P + k].detach().to(dev)
+        f32 = lambda k: pack.f32(g(k))
+        W = {}
+        emb_w, emb_b, self.emb_slices, off = [], [], {}, 0
+        mix, self.mix_index = [], {}
+
+        def add_emb(name, key):
+            nonlocal off
+            w = g(key + ".weight")
+            emb_w.append(pack.pack_linear(w)); emb_b.append(f32(key + ".bias"))
+            self.emb_slices[name] = (off, w.shape[0]); off += w.shape[0]
+
+        def add_mix(name, key):
+            self.mix_index[name] = len(mix); mix.append(g(key).reshape(()).float())
+
+        for k in ("time_embed.0", "time_embed.2", "label_emb.0.0", "label_emb.0.2"):
+            W[k + ".w"] = pack.pack_linear(g(k + ".weight")); W[k + ".b"] = f32(k + ".bias")
+        W["conv_in.w"] = pack.pack_conv3x3(g("input_blocks.0.0.weight"), cin_pad=CIN_PAD)
+        W["conv_in.b"] = f32("input_blocks.0.0.bias")
+
+        def pack_res(p):
+            for n in ("in_layers.0", "out_layers.0", "time_stack.in_layers.0", "time_stack.out_layers.0"):
+                W[f"{p}.{n}.g"] = f32(f"{p}.{n}.weight"); W[f"{p}.{n}.b"] = f32(f"{p}.{n}.bias")
+            for n in ("in_layers.2", "out_layers.3"):
+                W[f"{p}.{n}.w"] = pack.pack_conv3x3(g(f"{p}.{n}.weight")); W[f"{p}.{n}.b"] = f32(f"{p}.{n}.bias")
+                W[f"{p}.time_stack.{n}.w"] = pack.pack_convt3(g(f"{p}.time_stack.{n}.weight"))
+                W[f"{p}.time_stack.{n}.b"] = f32(f"{p}.time_stack.{n}.bias")
+            if (P + p + ".skip_connection.weight") in sd:
+                W[p + ".skip.w"] = pack.pack_conv1x1(g(p + ".skip_connection.weight"))
+                W[p + ".skip.b"] = f32(p + ".skip_connection.bias")
+            add_emb(p, p + ".emb_layers.1"); add_emb(p + ".time_stack", p + ".time_stack.emb_layers.1")
+            add_mix(p, p + ".time_mixer.mix_factor")
+
+        def pack_attn_block(p, with_ff_in):
+            for n in ("norm1", "norm3") + (("norm_in",) if with_ff_in else ()):
+                W[f"{p}.{n}.g"] = f32(f"{p}.{n}.weight"); W[f"{p}.{n}.b"] = f32(f"{p}.{n}.bias")
+            W[p + ".qkv.w"] = pack.pack_qkv(g(p + ".attn1.to_q.weight"), g(p + ".attn1.to_k.weight"), g(p + ".attn1.to_v.weight"))
+            W[p + ".o.w"] = pack.pack_linear(g(p + ".attn1.to_out.0.weight")); W[p + ".o.b"] = f32(p + ".attn1.to_out.0.bias")
+            # attn2 with a single context token: only to_v and to_out survive (norm2/to_q/to_k are dead)
+            W[p + ".x.v"] = pack.pack_linear(g(p + ".attn2.to_v.weight"))
+            W[p + ".x.o"] = pack.pack_linear(g(p + ".attn2.to_out.0.weight")); W[p + ".x.ob"] = f32(p + ".attn2.to_out.0.bias")
+            for ff in ("ff",) + (("ff_in",) if with_ff_in else ()):
+                W[f"{p}.{ff}.1.w"], W[f"{p}.{ff}.1.b"] = pack.pack_geglu(g(f"{p}.{ff}.net.0.proj.weight"), g(f"{p}.{ff}.net.0.proj.bias"))
+                W[f"{p}.{ff}.2.w"] = pack.pack_linear(g(f"{p}.{ff}.net.2.weight")); W[f"{p}.{ff}.2.b"] = f32(f"{p}.{ff}.net.2.bias")
+
+        def pack_transformer(p):
+            W[p + ".norm.g"] = f32(p + ".norm.weight"); W[p + ".norm.b"] = f32(p + ".norm.bias")
+            for n in ("proj_in", "proj_out", "time_pos_embed.0", "time_pos_embed.2"):
+                W[f"{p}.{n}.w"] = pack.pack_linear(g(f"{p}.{n}.weight")); W[f"{p}.{n}.b"] = f32(f"{p}.{n}.bias")
+            pack_attn_block(p + ".transformer_blocks.0", False)
+            pack_attn_block(p + ".time_stack.0", True)
+            add_mix(p, p + ".time_mixer.mix_factor")
+
+        self.transformers = []
+        blocks_in, middle, blocks_out = self.layout
+        named = [(f"input_blocks.{i}", L) for i, L in enumerate(blocks_in)] + [("middle_block", middle)] + \
+                [(f"output_blocks.{i}", L) for i, L in enumerate(blocks_out)]
+        for base, layers in named:
+            for j, L in enumerate(layers):
+                p = f"{base}.{j}"
+                if L[0] == "res":
+                    pack_res(p)
+                elif L[0] == "attn":
+                    pack_transformer(p); self.transformers.append((p, L[1]))
+                elif L[0] == "down":
+                    W[p + ".w"] = pack.pack_conv3x3(g(p + ".op.weight")); W[p + ".b"] = f32(p + ".op.bias")
+                elif L[0] == "up":
+                    W[p + ".w"] = pack.pack_conv3x3(g(p + ".conv.weight")); W[p + ".b"] = f32(p + ".conv.bias")
+        W["out.0.g"] = f32("out.0.weight"); W["out.0.b"] = f32("out.0.bias")
+        W["out.2.w"] = pack.pack_conv3x3(g("out.2.weight")); W["out.2.b"] = f32("out.2.bias")
+        W["emb_all.w"] = torch.cat(emb_w, 0).contiguous(); W["emb_all.b"] = torch.cat(emb_b, 0).contiguous()
+        self.emb_total = off
+        self.mix = torch.stack(mix)      # [n_mixers] raw mix_factor
+        self.W = W
+
+    # ------------------------------------------------------------------ helpers
+    def _linear(self, x, key, M, **kw):
+        w = self.W[key + ".w"]
+        return ops.gemm(x, w, M=M, N=w.shape[0], K=w.shape[1], bias=self.W.get(key + ".b"), **kw)
+
+    def _mlp_f32(self, x_bf16, k0, k2, M, rowvec=None):
+        """Linear -> SiLU -> Linear, fp32 result (time_embed / label_emb / time_pos_embed)."""
+        h = self._linear(x_bf16, k0, M, out_fp32=True)
+        return self._linear(ops.silu_to_bf16(h), k2, M, out_fp32=True, rowvec=rowvec, rows_per_group=1)
+
+    def _conditioning(self, context, F_, T):
+        """Per-transformer cross-attention vectors; recomputed only when `context` changes."""
+        key = (context.data_ptr(), context._version, tuple(context.shape), F_, T)
+        if self._cond_cache is not None and self._cond_cache[0] == key:
+            return self._cond_cache[1]
+        if context.dim() != 3 or context.shape[1] != 1:
+            raise ops._l.Hi3dError(
+                f"context must be [B,1,{self.cfg['context_dim']}] (one CLIP image token, "
+                f"sgm/modules/encoders/modules.py:1041-1046); got {tuple(context.shape)}")
+        ctx = context[:, 0].to(self.dev, torch.float32)
+        if ctx.shape[0] != F_:
+            ctx = ctx.repeat_interleave(F_ // ctx.shape[0], dim=0)     # "fast implementation" repeat
+        ctx_s = ctx.to(torch.bfloat16).contiguous()                    # spatial: per frame  [F, ctx]
+        ctx_t = ctx[::T].to(torch.bfloat16).contiguous()               # temporal: clip's first frame [B, ctx]
+        out = {}
+        for p, C in self.transformers:
+            for blk, cx in ((p + ".transformer_blocks.0", ctx_s), (p + ".time_stack.0", ctx_t)):
+                M = cx.shape[0]
+                v = ops.gemm(cx, self.W[blk + ".x.v"], M=M, N=C, K=cx.shape[1])
+                out[blk] = ops.gemm(v, self.W[blk + ".x.o"], M=M, N=C, K=C, bias=self.W[blk + ".x.ob"], out_fp32=True)
+        self._cond_cache = (key, out)
+        return out
+
+    def _pos_emb(self, p, C, B, T):
+        key = (p, B, T)
+        if key not in self._pos_cache:
+            frames = torch.arange(T, device=self.dev, dtype=torch.float32).repeat(B)
+            te = ops.timestep_embedding(frames, C, self.cfg.get("max_ddpm_temb_period", 10000), out_bf16=True)
+            self._pos_cache[key] = self._mlp_f32(te, p + ".time_pos_embed.0", p + ".time_pos_embed.2", B * T)
+        return self._pos_cache[key]
+
+    # ------------------------------------------------------------------ blocks
+    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all):
+        W, HW, B = self.W, H * Wd, F_ // T
+        M = F_ * HW
+        geo = dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0)
+        eo, _ = self.emb_slices[p]
+        h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5)
+        h = ops.gemm(h, W[p + ".in_layers.2.w"], M=M, N=Cout, K=9 * Cin, bias=W[p + ".in_layers.2.b"],
+                     rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, conv3x3=geo)
+        h = ops.groupnorm_silu(h, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.b"], F_, HW, Cout, 1e-5)
+        skip = x if (p + ".skip.w") not in W else self._linear(x, p + ".skip", M)
+        geo2 = dict(geo, Cin=Cout)
+        xs = ops.gemm(h, W[p + ".out_layers.3.w"], M=M, N=Cout, K=9 * Cout, bias=W[p + ".out_layers.3.b"],
+                      R1=skip, conv3x3=geo2)
+        # temporal ResBlock on the same memory: GroupNorm over (t,h,w) per clip, Conv3d (3,1,1)
+        q = p + ".time_stack"
+        eo, _ = self.emb_slices[q]
+        tg = dict(T=T, HW=HW, Cin=Cout)
+        h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5)
+        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=M, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
+                     rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, convt3=tg)
+        h = ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], B, T * HW, Cout, 1e-5)
+        # alpha*x_s + (1-alpha)*(x_s + h_t)  ==  x_s + (1-alpha)*h_t     (video_model.py:77-79)
+        return ops.gemm(h, W[q + ".out_layers.3.w"], M=M, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
+                        a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HW, convt3=tg)
+
+    def _transformer(self, p, x, C, F_, S, T, cond, a1_all, a_all):
+        W, B, M, Hh = self.W, F_ // T, F_ * S, C // 64
+        sp, tp = p + ".transformer_blocks.0", p + ".time_stack.0"
+        xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False)
+        h = self._linear(xn, p + ".proj_in", M)
+        # --- spatial block (attention.py:551-572)
+        n = ops.layernorm(h, W[sp + ".norm1.g"], W[sp + ".norm1.b"], M, C)
+        qkv = ops.gemm(n, W[sp + ".qkv.w"], M=M, N=3 * C, K=C)
+        a = ops.self_attention_fused_qkv(qkv, F_, S, Hh)
+        h = ops.gemm(a, W[sp + ".o.w"], M=M, N=C, K=C, bias=W[sp + ".o.b"], R1=h,
+                     rowvec=cond[sp], rows_per_group=S)                     # + attn1 + attn2 (one token)
+        n = ops.layernorm(h, W[sp + ".norm3.g"], W[sp + ".norm3.b"], M, C)
+        gg = ops.gemm(n, W[sp + ".ff.1.w"], M=M, N=8 * C, K=C, bias=W[sp + ".ff.1.b"], geglu=True)
+        h = ops.gemm(gg, W[sp + ".ff.2.w"], M=M, N=C, K=4 * C, bias=W[sp + ".ff.2.b"], R1=h)
+        # --- temporal block (video_attention.py:109-140), rows stay in (b t) s order
+        xm = torch.empty_like(h)
+        n = ops.layernorm(h, W[tp + ".norm_in.g"], W[tp + ".norm_in.b"], M, C, addvec=self._pos_emb(p, C, B, T),
+                          rows_per_group=S, sum_out=xm)                      # xm = h + frame-position emb
+        gg = ops.gemm(n, W[tp + ".ff_in.1.w"], M=M, N=8 * C, K=C, bias=W[tp + ".ff_in.1.b"], geglu=True)
+        xm = ops.gemm(gg, W[tp + ".ff_in.2.w"], M=M, N=C, K=4 * C, bias=W[tp + ".ff_in.2.b"], R1=xm)
+        n = ops.layernorm(xm, W[tp + ".norm1.g"], W[tp + ".norm1.b"], M, C)
+        qkv = ops.gemm(n, W[tp + ".qkv.w"], M=M, N=3 * C, K=C)
+        a = ops.attention_temporal_fused_qkv(qkv, B, T, S, Hh)
+        xm = ops.gemm(a, W[tp + ".o.w"], M=M, N=C, K=C, bias=W[tp + ".o.b"], R1=xm,
+                      rowvec=cond[tp], rows_per_group=T * S)
+        n = ops.layernorm(xm, W[tp + ".norm3.g"], W[tp + ".norm3.b"], M, C)
+        gg = ops.gemm(n, W[tp + ".ff.1.w"], M=M, N=8 * C, K=C, bias=W[tp + ".ff.1.b"], geglu=True)
+        i = self.mix_index[p]
+        # AlphaBlender: alpha*h + (1-alpha)*(ff(..)+xm)                      (video_attention.py:290-294)
+        h = ops.gemm(gg, W[tp + ".ff.2.w"], M=M, N=C, K=4 * C, bias=W[tp + ".ff.2.b"], R1=xm,
+                     a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=S)
+        return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward_tokens(self, x_tok, F_, H, Wd, timesteps, context, y, T, image_only_indicator):
+        """x_tok: bf16 [F*H*W, 64] (input channels zero-padded) -> fp32 [F*H*W, 4(out_channels)]."""
+        W, mc, dev = self.W, self.mc, self.dev
+        if F_ % T:
+            raise ops._l.Hi3dError("batch is not a multiple of num_video_frames")
+        B = F_ // T
+        # ---- embeddings (video_model.py:456-469)
+        te = ops.timestep_embedding(timesteps.to(dev), mc, 10000.0, out_bf16=True)
+        t_emb = self._mlp_f32(te, "time_embed.0", "time_embed.2", F_)
+        yb = y.to(dev, torch.float32)
+        if yb.shape[0] != F_:
+            yb = yb.repeat_interleave(F_ // yb.shape[0], dim=0)
+        emb = self._mlp_f32(yb.to(torch.bfloat16).contiguous(), "label_emb.0.0", "label_emb.0.2", F_, rowvec=t_emb)
+        emb_all = self._linear(ops.silu_to_bf16(emb), "emb_all", F_, out_fp32=True)     # all 44 emb_layers at once
+        cond = self._conditioning(context, F_, T)
+        # ---- AlphaBlender factors per frame (util.py:341-357)
+        ioi = image_only_indicator.to(dev).reshape(1, F_) > 0
+        a_all = torch.where(ioi, torch.ones((), device=dev), torch.sigmoid(self.mix)[:, None]).contiguous()
+        a1_all = (1.0 - a_all).contiguous()
+
+        blocks_in, middle, blocks_out = self.layout
+        h, hs = x_tok, []
+        cur = {"H": H, "W": Wd, "C": CIN_PAD}
+
+        def run(h, layers, base):
+            for j, L in enumerate(layers):
+                p = f"{base}.{j}"
+                Hc, Wc = cur["H"], cur["W"]
+                if L[0] == "conv_in":
+                    h = ops.gemm(h, W["conv_in.w"], M=F_ * Hc * Wc, N=mc, K=9 * CIN_PAD, bias=W["conv_in.b"],
+                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
+                    cur["C"] = mc
+                elif L[0] == "res":
+                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all)
+                    cur["C"] = L[2]
+                elif L[0] == "attn":
+                    h = self._transformer(p, h, L[1], F_, Hc * Wc, T, cond, a1_all, a_all)
+                elif L[0] == "down":
+                    Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+                    h = ops.gemm(h, W[p + ".w"], M=F_ * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"],
+                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=Ho, Wout=Wo, stride=2, up2x=0))
+                    cur["H"], cur["W"] = Ho, Wo
+                elif L[0] == "up":
+                    h = ops.gemm(h, W[p + ".w"], M=F_ * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
+                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
+                    cur["H"], cur["W"] = 2 * Hc, 2 * Wc
+            return h
+
+        for i, layers in enumerate(blocks_in):
+            h = run(h, layers, f"input_blocks.{i}")
+            hs.append((h, cur["C"]))
+        h = run(h, middle, "middle_block")
+        for i, layers in enumerate(blocks_out):
+            s, sc = hs.pop()
+            h = ops.concat_channels(h, s, F_ * cur["H"] * cur["W"], cur["C"], sc)     # th.cat (video_model.py:491)
+            h = run(h, layers, f"output_blocks.{i}")
+        Hc, Wc = cur["H"], cur["W"]
+        h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], F_, Hc * Wc, mc, 1e-5)
+        oc = self.cfg["out_channels"]
+        if oc % 4:
+            raise ops._l.Hi3dError("out_channels must be a multiple of 4")
+        return ops.gemm(h, W["out.2.w"], M=F_ * Hc * Wc, N=oc, K=9 * mc, bias=W["out.2.b"], out_fp32=True,
+                        conv3x3=dict(Hin=Hc, Win=Wc, Cin=mc, Hout=Hc, Wout=Wc, stride=1, up2x=0))
+
+    @torch.no_grad()
+    def forward_nchw(self, x, timesteps, context, y, T, image_only_indicator):
+        """Reference-shaped entry: x [F, Cin, H, W] (any float dtype) -> [F, out_ch, H, W] fp32."""
+        F_, Cin, H, Wd = x.shape
+        if Cin != self.cfg["in_channels"]:
+            raise ops._l.Hi3dError(f"expected {self.cfg['in_channels']} input channels, got {Cin}")
+        tok = ops.nchw_to_tokens(x.to(self.dev), CIN_PAD)
+        out = self.forward_tokens(tok, F_, H, Wd, timesteps, context, y, T, image_only_indicator)
+        return ops.tokens_to_nchw(out, F_, self.cfg["out_channels"], H, Wd, self.cfg["out_channels"])

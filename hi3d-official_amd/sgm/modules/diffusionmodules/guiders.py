@@ -1,0 +1,48 @@
+"""Classifier-free guidance with a per-frame linear scale (reference: guiders.py:60-99)."""
+import torch
+
+from ...util import append_dims
+
+
+class IdentityGuider:
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_inputs(self, x, s, c, uc):
+        return x, s, {k: c[k] for k in c}
+
+
+class LinearPredictionGuider:
+    def __init__(self, max_scale, num_frames, min_scale=1.0, additional_cond_keys=None):
+        self.min_scale, self.max_scale, self.num_frames = min_scale, max_scale, num_frames
+        self.scale = torch.linspace(min_scale, max_scale, num_frames).unsqueeze(0)
+        if additional_cond_keys is None:
+            additional_cond_keys = []
+        elif isinstance(additional_cond_keys, str):
+            additional_cond_keys = [additional_cond_keys]
+        self.additional_cond_keys = list(additional_cond_keys)
+        self._scale_dev = {}
+
+    def _scale_on(self, device):
+        if device not in self._scale_dev:
+            self._scale_dev[device] = self.scale.to(device)
+        return self._scale_dev[device]
+
+    def __call__(self, x, sigma):
+        T = self.num_frames
+        x_u, x_c = x.chunk(2)
+        b = x_u.shape[0] // T
+        scale = append_dims(self._scale_on(x.device).expand(b, T), x_u.ndim + 1).to(x.dtype)
+        x_u, x_c = x_u.reshape((b, T) + x_u.shape[1:]), x_c.reshape((b, T) + x_c.shape[1:])
+        return (x_u + scale * (x_c - x_u)).reshape((b * T,) + x_u.shape[2:])
+
+    def prepare_inputs(self, x, s, c, uc):
+        doubled = ["vector", "crossattn", "concat"] + self.additional_cond_keys
+        c_out = {}
+        for k in c:
+            if k in doubled:
+                c_out[k] = torch.cat((uc[k], c[k]), 0)
+            else:
+                assert c[k] == uc[k]
+                c_out[k] = c[k]
+        return torch.cat([x, x]), torch.cat([s, s]), c_out

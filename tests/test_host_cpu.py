@@ -1,0 +1,147 @@
+"""CPU-side checks: the parameter containers reproduce the reference's state_dict
+layout, the C-ABI library loads and exports every declared symbol, host-side sampler
+logic matches the oracle.  No GPU, no kernel launches."""
+import os
+import re
+
+import pytest
+import torch
+
+from hi3d_hip import lib as hlib
+from hi3d_hip import pack, synth
+from oracle import hi3d_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "hi3d_hip.h")).read()
+    declared = set(re.findall(r"\b(hi3d_[a-z0-9_]+)\s*\(", header))
+    declared -= {"hi3d_gemm_desc"}
+    lib = hlib.load()
+    assert lib.hi3d_abi_version() == 1
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hi3d_hip.h but not exported"
+    assert declared == set(hlib.EXPORTS), declared ^ set(hlib.EXPORTS)
+
+
+def test_gemm_desc_layout_matches_header():
+    """ctypes struct field order/types mirror `hi3d_gemm_desc`."""
+    header = open(os.path.join(ROOT, "include", "hi3d_hip.h")).read()
+    body = header[header.index("typedef struct hi3d_gemm_desc {"):header.index("} hi3d_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S).replace("typedef struct hi3d_gemm_desc {", "")
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.split(",")
+        first = parts[0].split()
+        names.append(first[-1].lstrip("*"))
+        names += [p.strip().lstrip("*") for p in parts[1:]]
+    assert names == [f[0] for f in hlib.GemmDesc._fields_]
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_s1", "unet_s1_lat16", "unet_s2_lat16"])
+def test_unet_param_tree_matches_reference_state_dict(name):
+    from sgm.modules.diffusionmodules.video_model import unet_param_shapes
+    fx = load(name)
+    mine = {k: tuple(v) for k, v in unet_param_shapes(fx["cfg"]).items()}
+    assert mine == {k: tuple(v) for k, v in fx["shapes"].items()}
+
+
+def test_unet_module_state_dict_and_unsupported_options():
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    fx = load("unet_tiny_s1")
+    m = VideoUNet(**fx["cfg"])
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in fx["shapes"].items()}
+    synth.fill_module_(m, 1, prefix=fx["key_prefix"])
+    for k, v in fx["probe"].items():
+        assert torch.equal(m.state_dict()[k].flatten()[:4], v)
+    with pytest.raises(NotImplementedError, match="num_head_channels"):
+        VideoUNet(**dict(fx["cfg"], num_head_channels=32))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(8, 8, 16, 16), torch.zeros(8), context=torch.zeros(2, 1, 1024), y=torch.zeros(2, 768), num_video_frames=4)
+
+
+@pytest.mark.parametrize("name", ["vae_tiny", "vae_full_lat8"])
+def test_vae_param_tree_matches_reference_state_dict(name):
+    from sgm.models.autoencoder import vae_param_shapes
+    fx = load(name)
+    assert {k: tuple(v) for k, v in vae_param_shapes(fx["ddconfig"], 4).items()} == fx["shapes"]
+
+
+def test_pack_geglu_and_conv_layouts():
+    w = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3)
+    b = torch.arange(8, dtype=torch.float32)
+    wp, bp = pack.pack_geglu(w, b)      # inner = 4: rows x0 x1 g0 g1 x2 x3 g2 g3
+    assert bp.tolist() == [0, 1, 4, 5, 2, 3, 6, 7]
+    assert torch.equal(wp.float(), w[[0, 1, 4, 5, 2, 3, 6, 7]])
+    c = torch.randn(5, 3, 3, 3)
+    p = pack.pack_conv3x3(c, cin_pad=8).float().reshape(5, 3, 3, 8)
+    assert torch.equal(p[..., :3], c.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and p[..., 3:].abs().sum() == 0
+    t = torch.randn(4, 6, 3, 1, 1)
+    pt = pack.pack_convt3(t).float().reshape(4, 3, 6)
+    assert torch.equal(pt, t[..., 0, 0].permute(0, 2, 1).to(torch.bfloat16).float())
+
+
+def test_sampler_host_logic_matches_oracle_with_analytic_denoiser():
+    """EulerEDMSampler + LinearPredictionGuider + Denoiser on CPU with a closed-form
+    'network' (so no kernels are needed): same trajectory as the oracle's loop."""
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    T, steps = 4, 6
+    sampler = EulerEDMSampler(
+        num_steps=steps, device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": 2.5, "min_scale": 1.0}})
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    x0, c, uc = synth.synth_conditioning(T, 6, 6, stage=1, seed=3)
+
+    def network(x, c_noise, cond, **kw):     # any deterministic function of its inputs
+        return torch.tanh(x) * c_noise.reshape(-1, 1, 1, 1) + cond["concat"].mean(1, keepdim=True) + cond["vector"].mean()
+
+    out = sampler(lambda i, s, cc: den(network, i, s, cc), x0.clone(), cond=c, uc=uc)
+    # oracle loop with the same analytic network
+    sig = O.edm_sigmas(steps)
+    assert torch.allclose(sampler.discretization(steps), sig)
+    x = x0 * torch.sqrt(1 + sig[0] ** 2)
+    scale = torch.linspace(1.0, 2.5, T).reshape(T, 1, 1, 1)
+    for i in range(steps):
+        s = sig[i]
+        c_skip, c_out, c_in, c_noise = 1 / (s * s + 1), -s / (s * s + 1) ** 0.5, 1 / (s * s + 1) ** 0.5, 0.25 * s.log()
+        xx = torch.cat([x, x])
+        cond = {"concat": torch.cat([uc["concat"], c["concat"]]), "vector": torch.cat([uc["vector"], c["vector"]])}
+        d = network(xx * c_in, c_noise.repeat(2 * T), cond) * c_out + xx * c_skip
+        du, dc = d.chunk(2)
+        d = du + scale * (dc - du)
+        x = x + (sig[i + 1] - s) * (x - d) / s
+    assert torch.allclose(out, x, rtol=1e-5, atol=1e-5)
+
+
+def test_create_model_from_yaml_builds_engine():
+    from vtdm.model import create_model
+    cfg = os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml")
+    if not os.path.exists(cfg):
+        pytest.skip("configs not written yet")
+    import yaml
+    y = yaml.safe_load(open(cfg))
+    # shrink widths so the CPU test stays cheap; structure/keys are what is checked
+    y["model"]["params"]["network_config"]["params"]["model_channels"] = 64
+    y["model"]["params"]["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as fh:
+        yaml.safe_dump(y, fh)
+    m = create_model(fh.name)
+    keys = list(m.state_dict())
+    assert any(k.startswith("model.diffusion_model.input_blocks.0.0.weight") for k in keys)
+    assert any(k.startswith("first_stage_model.decoder.conv_in.weight") for k in keys)
+    assert m.num_samples == 16 and m.sampler.num_steps == 25 and m.sampler.guider.max_scale == 2.5
+    assert abs(m.scale_factor - 0.18215) < 1e-9 and m.en_and_decode_n_samples_a_time == 16
