@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Benchmark of the Hi3D denoising hot path on MI355X.
+
+metric : denoise-steps/sec (one step = one EulerEDMSampler.sampler_step = CFG-doubled
+         VideoUNet forward at batch 2*T + guider + Euler update), BASELINE.json.
+workload (N=1): stage-2 refiner, 16 views @ 1024x1024 (latent 128x128, in_channels 17),
+         bf16 storage / fp32 accumulate, random-init weights of the full 1.52 B-parameter
+         architecture (hi3d_hip.synth), synthetic conditioning, inputs resident in HBM.
+         `--config s1` selects stage-1 (16 views @ 512x512) instead.
+N > 1  : one process per GPU (torchrun); every rank denoises an independent orbit clip
+         (replicas -- the unit that shards with no data-path collective);
+         value = steps of all ranks / max-over-ranks time; "scaling": "weak".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hi3d-official_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def unet_cfg(stage, mc=320):
+    return dict(in_channels=8 if stage == 1 else 17, model_channels=mc, out_channels=4, num_res_blocks=2,
+                attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_head_channels=64,
+                use_linear_in_transformer=True, transformer_depth=1, context_dim=1024,
+                spatial_transformer_attn_type="softmax-xformers", extra_ff_mix_layer=True, use_spatial_context=True,
+                merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1], num_classes="sequential",
+                adm_in_channels=768 if stage == 1 else 512, use_checkpoint=True)
+
+
+# algorithmic work per denoise step of the reference-equivalent graph
+STEP_TFLOP = {1: 40.61, 2: 209.47}
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["s1", "s2"], default="s2")
+    ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists in this framework)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hi3d_hip import ops, synth
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+
+    stage = 1 if a.config == "s1" else 2
+    T = a.views
+    lat = 64 if stage == 1 else 128
+    cfg = unet_cfg(stage)
+    t0 = time.time()
+    unet = VideoUNet(**cfg)
+    synth.fill_module_(unet, seed=1, prefix="model.diffusion_model.")
+    cpu_sd = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_sd = {"model.diffusion_model." + k: v.clone() for k, v in unet.state_dict().items()}
+    unet = unet.to(dev)
+    model = OpenAIWrapper(unet)
+    unet.runtime(dev)                      # one-time weight re-layout
+    log(f"[bench] rank {rank}: model built + packed in {time.time() - t0:.1f}s")
+
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = EulerEDMSampler(
+        num_steps=25, device=dev, verbose=False,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                               "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": 2.5 if stage == 1 else 2.0, "min_scale": 1.0}})
+    x0, c, uc = synth.synth_conditioning(T, lat, lat, stage=stage, seed=rank)    # a different clip per rank
+    c = {k: v.to(dev) for k, v in c.items()}
+    uc = {k: v.to(dev) for k, v in uc.items()}
+    extra = dict(image_only_indicator=torch.zeros(2, T, device=dev), num_video_frames=T)
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+
+    x, s_in, sigmas, num_sigmas, cond, ucond = sampler.prepare_sampling_loop(x0.to(dev), c, uc)
+    n_sched = num_sigmas - 1
+
+    def step(i, x):
+        return sampler.step_call(denoiser, x, i % n_sched, s_in, sigmas, num_sigmas, cond, ucond)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(a.warmup):
+        x = step(i, x)
+    prof = None if a.no_profile else ops.Profiler()
+    barrier(); torch.cuda.synchronize()
+    ops.PROFILER = prof
+    t_start = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        x = step(i, x)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t_start
+    ops.PROFILER = None
+    if not torch.isfinite(x).all():
+        raise SystemExit("non-finite latents after the timed steps")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * a.steps / elapsed
+    out = {
+        "metric": "denoise-steps/sec (UNet fwd) at 16 views x 1024^2" if stage == 2 and T == 16
+                  else f"denoise-steps/sec (UNet fwd) at {T} views x {lat * 8}^2",
+        "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Hi3D stage-{stage} VideoUNet sampler step, {T} views @ {lat * 8}x{lat * 8} "
+                               f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
+                               "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
+                   "global_batch": 2 * T * world, "parallelism": f"replicas x{world} (one clip per GPU)"},
+    }
+    step_tf = STEP_TFLOP[stage] * (T / 16.0)
+    out["step_roofline"] = {"bound": "mfma", "achieved": round(step_tf / (ms_per_step / 1e3), 1),
+                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(step_tf / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
+                            "note": "whole step: reference-equivalent algorithmic TFLOP / wall time"}
+    if prof is not None:
+        summ = prof.summary()
+        total_ms = sum(d["ms"] for d in summ.values())
+        fams = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
+        for fam, d in fams:
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            log(f"[bench] {fam:16s} {d['ms'] / a.steps:9.3f} ms/step  {d['launches'] // a.steps:4d} launches/step  "
+                f"{tf:8.1f} TFLOP/s  {gbs:8.1f} GB/s(alg)")
+        log(f"[bench] kernels total {total_ms / a.steps:.2f} ms/step of {ms_per_step:.2f} ms/step wall")
+        # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
+        g = [d for f, d in summ.items() if f.startswith("gemm_")]
+        g_ms, g_fl, g_n = sum(d["ms"] for d in g), sum(d["flops"] for d in g), sum(d["launches"] for d in g)
+        at = summ.get("attn_d64", dict(ms=0.0, flops=0.0, launches=1))
+        dom_is_gemm = g_ms >= at["ms"]
+        k_ms, k_fl, k_n = (g_ms, g_fl, g_n) if dom_is_gemm else (at["ms"], at["flops"], at["launches"])
+        ach = k_fl / (k_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel",
+                           "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": k_n // a.steps, "avg_launch_ms": round(k_ms / k_n, 4),
+                           "share_of_step": round(k_ms / a.steps / ms_per_step, 3)}
+        out["kernels_ms_per_step"] = {f: round(d["ms"] / a.steps, 3) for f, d in fams}
+        if "attn_d64" in summ:
+            d = summ["attn_d64"]
+            out["attention_mfma"] = {"achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        for fam in ("groupnorm_silu", "layernorm"):
+            if fam in summ:
+                d = summ[fam]
+                out[fam + "_hbm"] = {"achieved": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                     "unit": "GB/s", "frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        step_flops_exec = sum(d["flops"] for d in summ.values()) / a.steps
+    else:
+        step_flops_exec = None
+
+    if cpu_sd is not None:
+        out["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
+    """Oracle (oracle/hi3d_oracle.py, fp32 torch CPU kernels = the reference's CPU path
+    restated) timed on this box's host cores on a bounded sample of the same step: the
+    full-width UNet at T=4, latent 16x16, extrapolated to the full step by executed FLOPs."""
+    from hi3d_hip import ops
+    from oracle import hi3d_oracle as O
+    T, hw = 4, 16
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2 * T, cfg["in_channels"], hw, hw), generator=g)
+    ts = torch.full((2 * T,), 0.25 * 1.5)
+    ctx, y = torch.randn((2, 1, 1024), generator=g), torch.randn((2, cfg["adm_in_channels"]), generator=g)
+    ioi = torch.zeros(2, T)
+    # executed FLOPs of the sample, counted by the same per-launch formulae as the GPU path
+    prof = ops.Profiler(); ops.PROFILER = prof
+    unet(x.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T, image_only_indicator=ioi.to(dev))
+    torch.cuda.synchronize(); ops.PROFILER = None
+    sample_flops = sum(d["flops"] for d in prof.summary().values())
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")
+    dt = time.perf_counter() - t0
+    cpu_tflops = sample_flops / dt / 1e12
+    full = step_flops_exec if step_flops_exec else step_tf * 1e12
+    return {"value": round(cpu_tflops * 1e12 / full, 6), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 UNet forward, full width, T=4, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP in "
+                      f"{dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {cores} threads), extrapolated to the "
+                      f"{full / 1e12:.1f} TFLOP executed per full step",
+            "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

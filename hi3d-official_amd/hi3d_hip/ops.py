@@ -18,6 +18,36 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+class Profiler:
+    """Per-kernel timing with HIP events on the stream the kernels are launched on
+    (torch's current stream), plus the algorithmic FLOPs / bytes of each launch.
+    Enabled by bench.py / tests only; `None` (default) costs one attribute read per op."""
+
+    def __init__(self):
+        self.records = []       # (family, flops, bytes, start_event, end_event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, family, flops, nbytes, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((family, float(flops), float(nbytes), start, e))
+
+    def summary(self):
+        """{family: dict(ms, launches, flops, bytes)} -- call after a device sync."""
+        out = {}
+        for fam, fl, nb, s, e in self.records:
+            d = out.setdefault(fam, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += s.elapsed_time(e); d["launches"] += 1; d["flops"] += fl; d["bytes"] += nb
+        return out
+
+
+PROFILER = None   # set to a Profiler() to record
+
+
 def _chk_dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -57,7 +87,12 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])
     else:
         d.amode = _l.A_DENSE
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")
+    if prof:
+        fam = ("gemm_conv3x3" if conv3x3 is not None else "gemm_convt3" if convt3 is not None else "gemm_dense")
+        prof.end(fam, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), t0)
     return out
 
 
@@ -65,7 +100,11 @@ def transpose_v(v_view, B, H, S, ldv):
     """v_view: tensor whose data_ptr is V[b=0,s=0,h=0,d=0]; returns vt [B,H,64,S_pad]."""
     S_pad = (S + 63) // 64 * 64
     vt = torch.empty((B, H, 64, S_pad), device=v_view.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_transpose_v(_p(v_view), _p(vt), B, H, S, S_pad, ldv, _stream()), "hi3d_transpose_v")
+    if prof:
+        prof.end("transpose_v", 0.0, 2.0 * 2 * B * H * S * 64, t0)
     return vt
 
 
@@ -73,8 +112,12 @@ def attention_d64(q, k, vt, B, H, S_q, S_kv, ldq, ldk, scale, out=None):
     _chk_dev(q, k, vt, out)
     if out is None:
         out = torch.empty((B * S_q, H * 64), device=q.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_attn_d64(_p(q), _p(k), _p(vt), _p(out), B, H, S_q, S_kv, ldq, ldk,
                                 vt.shape[-1], out.stride(0), float(scale), _stream()), "hi3d_attn_d64")
+    if prof:
+        prof.end("attn_d64", 4.0 * B * H * S_q * S_kv * 64, 2.0 * B * H * 64 * (2 * S_q + 2 * S_kv), t0)
     return out
 
 
@@ -93,9 +136,13 @@ def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
     assert qkv.shape == (B * T * S, 3 * C) and qkv.is_contiguous()
     scale = 64 ** -0.5 if scale is None else scale
     out = torch.empty((B * T * S, C), device=qkv.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_attn_temporal_d64(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), _p(out),
                                          B, T, S, H, 3 * C, C, float(scale), _stream()),
              "hi3d_attn_temporal_d64")
+    if prof:
+        prof.end("attn_temporal", 4.0 * B * S * H * T * T * 64, 2.0 * 4 * B * T * S * C, t0)
     return out
 
 
@@ -114,8 +161,12 @@ def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 16), device=x.device, dtype=torch.float32)
         _gn_ws[key] = ws
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_groupnorm_silu(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
                                       float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu")
+    if prof:   # algorithmic bytes: read x once + write y once; the kernel reads x twice
+        prof.end("groupnorm_silu", 0.0, 2.0 * 2 * inst * P * C, t0)
     return out
 
 
@@ -123,14 +174,22 @@ def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum
     _chk_dev(x, gamma, beta, addvec, sum_out, out)
     if out is None:
         out = torch.empty((R, C), device=x.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_layernorm(_p(x), _p(out), _p(sum_out), _p(gamma), _p(beta), _p(addvec),
                                  rows_per_group, R, C, float(eps), _stream()), "hi3d_layernorm")
+    if prof:
+        prof.end("layernorm", 0.0, 2.0 * R * C * (3 if sum_out is not None else 2), t0)
     return out
 
 
 def concat_channels(a, b, rows, C0, C1):
     out = torch.empty((rows, C0 + C1), device=a.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_concat_channels(_p(a), _p(b), _p(out), rows, C0, C1, _stream()), "hi3d_concat_channels")
+    if prof:
+        prof.end("concat_channels", 0.0, 2.0 * 2 * rows * (C0 + C1), t0)
     return out
 
 
