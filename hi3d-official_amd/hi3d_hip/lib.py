@@ -6,6 +6,10 @@ import of `ops` fails loudly -- there is no PyTorch / CPU fallback.
 import ctypes as C
 import os
 
+# torch must be loaded first: it ships its own libamdhip64 and our library has to bind to
+# that same HIP runtime instance (device pointers and streams come from torch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhi3d_hip.so")
 

@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks at the real Hi3D stage-2 / stage-1 shapes (no model build).
+usage: python tools/kbench.py [gemm|conv|attn|norm|all] [--s1]
+Prints one line per shape: ms, TFLOP/s or GB/s.  Random data (never zero-filled)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hi3d-official_amd"))
+import torch  # noqa: E402
+
+from hi3d_hip import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def rb(*shape):
+    return (torch.randn(shape, device=dev) * 0.5).to(torch.bfloat16)
+
+
+def bench_gemm(F=32, lat=128):
+    print("== dense GEMM (M,N,K,kind)")
+    for ds, C in ((1, 320), (2, 640), (4, 1280)):
+        M = F * (lat // ds) ** 2
+        for name, N, K, kw in (("qkv", 3 * C, C, {}), ("proj", C, C, {"res": True}), ("geglu", 8 * C, C, {"geglu": True}),
+                               ("ff2", C, 4 * C, {"res": True})):
+            A, W = rb(M, K), rb(N, K)
+            bias = torch.randn(N, device=dev)
+            R1 = rb(M, N) if kw.get("res") else None
+            out = torch.empty((M, N // 2 if kw.get("geglu") else N), device=dev, dtype=torch.bfloat16)
+            ms = timeit(lambda: ops.gemm(A, W, M=M, N=N, K=K, bias=bias, R1=R1, geglu=bool(kw.get("geglu")), out=out))
+            print(f"  {name:6s} M={M:7d} N={N:5d} K={K:5d}: {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s")
+
+
+def bench_conv(F=32, lat=128):
+    print("== conv3x3 implicit GEMM (H, Cin, Cout)")
+    for H, Cin, Cout in ((lat, 320, 320), (lat, 640, 320), (lat, 960, 320), (lat // 2, 640, 640), (lat // 2, 1280, 640),
+                         (lat // 4, 1280, 1280), (lat // 4, 2560, 1280), (lat // 8, 1280, 1280)):
+        M, K = F * H * H, 9 * Cin
+        A, W = rb(M, Cin), rb(Cout, K)
+        bias = torch.randn(Cout, device=dev)
+        out = torch.empty((M, Cout), device=dev, dtype=torch.bfloat16)
+        geo = dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up2x=0)
+        ms = timeit(lambda: ops.gemm(A, W, M=M, N=Cout, K=K, bias=bias, conv3x3=geo, out=out))
+        print(f"  H={H:4d} {Cin:5d}->{Cout:5d}: {ms:8.3f} ms  {2.0 * M * Cout * K / ms / 1e9:8.1f} TFLOP/s")
+    print("== conv temporal (3,1,1)")
+    for H, C in ((lat, 320), (lat // 2, 640), (lat // 4, 1280)):
+        M, K = F * H * H, 3 * C
+        A, W = rb(M, C), rb(C, K)
+        out = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
+        ms = timeit(lambda: ops.gemm(A, W, M=M, N=C, K=K, convt3=dict(T=16, HW=H * H, Cin=C), out=out))
+        print(f"  H={H:4d} C={C:5d}: {ms:8.3f} ms  {2.0 * M * C * K / ms / 1e9:8.1f} TFLOP/s")
+
+
+def bench_attn(F=32, lat=128):
+    print("== spatial attention d64 (B,H,S)")
+    for ds, C in ((1, 320), (2, 640), (4, 1280)):
+        S, H = (lat // ds) ** 2, C // 64
+        qkv = rb(F * S, 3 * C)
+        vt = ops.transpose_v(qkv[:, 2 * C:], F, H, S, 3 * C)
+        out = torch.empty((F * S, C), device=dev, dtype=torch.bfloat16)
+        ms = timeit(lambda: ops.attention_d64(qkv, qkv[:, C:], vt, F, H, S, S, 3 * C, 3 * C, 0.125, out=out), iters=5)
+        print(f"  B={F} H={H:2d} S={S:6d}: {ms:8.3f} ms  {4.0 * F * H * S * S * 64 / ms / 1e9:8.1f} TFLOP/s")
+    print("== temporal attention")
+    for ds, C in ((1, 320), (2, 640), (4, 1280)):
+        S, H = (lat // ds) ** 2, C // 64
+        qkv = rb(F * S, 3 * C)
+        ms = timeit(lambda: ops.attention_temporal_fused_qkv(qkv, 2, F // 2, S, H))
+        print(f"  S={S:6d} H={H:2d}: {ms:8.3f} ms  {2.0 * 4 * F * S * C / ms / 1e6:8.1f} GB/s(q,k,v,o)")
+
+
+def bench_norm(F=32, lat=128):
+    print("== GroupNorm+SiLU (2-D: inst=F ; 3-D: inst=2)")
+    for ds, C in ((1, 320), (1, 960), (2, 640), (4, 1280), (4, 2560)):
+        P = (lat // ds) ** 2
+        x = rb(F * P, C)
+        g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        out = torch.empty_like(x)
+        for inst, PP in ((F, P), (2, F // 2 * P)):
+            ms = timeit(lambda: ops.groupnorm_silu(x, g, b, inst, PP, C, 1e-5, True, out=out))
+            print(f"  inst={inst:3d} P={PP:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * F * P * C / ms / 1e6:8.1f} GB/s(alg r+w)")
+    print("== LayerNorm")
+    for ds, C in ((1, 320), (2, 640), (4, 1280)):
+        R = F * (lat // ds) ** 2
+        x = rb(R, C)
+        g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: ops.layernorm(x, g, b, R, C, out=out))
+        print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    lat = 64 if "--s1" in sys.argv else 128
+    if which in ("gemm", "all"):
+        bench_gemm(lat=lat)
+    if which in ("conv", "all"):
+        bench_conv(lat=lat)
+    if which in ("attn", "all"):
+        bench_attn(lat=lat)
+    if which in ("norm", "all"):
+        bench_norm(lat=lat)
