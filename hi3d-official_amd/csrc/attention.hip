@@ -35,6 +35,7 @@ struct AttnParams {
 };
 
 constexpr int KV_TILE = 64;
+constexpr float RESCALE_THR = 6.0f;   // log2 domain
 constexpr int ATT_STAGE = 2 * KV_TILE * 128;   // K tile 8 KiB + V^T tile 8 KiB
 
 __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
@@ -123,14 +124,13 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 
     // S^T = K Q^T  (two 32-key blocks)
     f32x16 sc[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
-#pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(s + k_off[kb] + (((ks * 2 + hi) ^ k_sw) << 4));
-        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
       }
     }
     // lane registers: sc[kb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
-          if (kv >= p.Skv) sc[kb][r] = -INFINITY;
+          sc[kb][r] = (kv >= p.Skv) ? -INFINITY : sc[kb][r];
         }
     }
     float mx = sc[0][0];
@@ -149,9 +149,21 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);   // finite: every tile has >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: keep the old running max while the tile max exceeds it by at most
+    // 2^RESCALE_THR (P then stays <= 2^THR, harmless for bf16 P / fp32 accumulators); the
+    // branch is wave-uniform.  The very first tile always rescales (m_run = -inf).
+    const float m_tile = mx * p.scale_log2;                // finite: every tile has >= 1 valid key
+    float alpha = 1.0f;
+    if (!__all(m_tile - m_run <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, m_tile);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    const float m_new = m_run;
     float psum = 0.f;
     bf16x8 pf[4];
 #pragma unroll
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
         float e[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          e[t] = exp2f(sc[kb][half * 8 + t] * p.scale_log2 - m_new);
+          e[t] = __builtin_amdgcn_exp2f(sc[kb][half * 8 + t] * p.scale_log2 - m_new);
           psum += e[t];
         }
         union { bf16x8 v; unsigned int u[4]; } pk;
@@ -170,10 +182,6 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
         pf[kb * 2 + half] = pk.v;
       }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
 
     // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile)
 #pragma unroll

@@ -20,15 +20,16 @@ static __device__ uint4 hi3d_zero_page[16];  // zero-initialised, one copy per T
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) {
   return __uint_as_float(((unsigned int)u) << 16);
 }
-// round-to-nearest-even, NaN preserved (quiet)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+// fp32 -> bf16 through the gfx950 hardware converter (v_cvt_pk_bf16_f32: round to
+// nearest even, NaN preserved); written as native __bf16 casts so hipcc emits it.
+typedef __attribute__((ext_vector_type(2))) __bf16 hi3d_bf2;
+typedef __attribute__((ext_vector_type(2))) float hi3d_f2;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  const hi3d_f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hi3d_bf2));
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  return (unsigned short)(pack_bf16x2(f, 0.0f) & 0xffffu);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) {
