@@ -16,6 +16,7 @@
 // so every lane ends up holding 4*NT *consecutive* output columns of one output
 // row: the epilogue reads residuals and writes results 8 bytes at a time.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,6 +31,23 @@ struct GemmParams {
 
 constexpr int BM = 128, BK = 64;
 
+// The kernel can walk a contiguous range of tiles per block (persistent form, next tile's
+// loads in flight during the epilogue).  On MI355X the dynamic one-block-per-tile dispatch
+// measured faster (hardware staggers co-resident blocks; persistent blocks run in lockstep),
+// so the default grid is one block per tile; HI3D_GEMM_BLOCKS_PER_CU=k selects k*CUs blocks.
+int persistent_grid() {
+  static int g = 0;
+  if (g == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const char* e = getenv("HI3D_GEMM_BLOCKS_PER_CU");   // tuning knob (0 = one block per tile)
+    const int per_cu = e ? atoi(e) : 0;   // measured: one block per tile beats the persistent range at every Hi3D shape
+    g = per_cu > 0 ? per_cu * cus : 0x7fffffff;
+  }
+  return g;
+}
+
 template <int NT, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int BN = 32 * NT;
@@ -42,64 +60,74 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
 
-  // ---- block -> tile, XCD-aware: consecutive logical ids (which share the A tile
-  // and sweep W) stay on one XCD's L2.  Bijective for any grid size.
-  const int nblk = p.nbm * p.nbn;
+  // ---- persistent block: a contiguous range of output tiles (n fastest, so consecutive
+  // tiles re-read the same activation rows from L2).  Blocks are renumbered XCD-aware
+  // (bijective for any grid) so that neighbouring ranges share one XCD's L2.
+  const int tiles_total = p.nbm * p.nbn;
+  const int nblk = gridDim.x;
   int lid;
   {
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = lid % p.nbn, tm = lid / p.nbn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int tpb = (tiles_total + nblk - 1) / nblk;
+  const int tile_begin = lid * tpb;
+  const int tile_end = min(tiles_total, tile_begin + tpb);
+  if (tile_begin >= tile_end) return;
 
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
   // (r&7 within an 8-row, 1 KiB DMA piece); lane slot s carries source chunk
-  // s ^ swz(r).
+  // s ^ swz(r).  Chunk assignment is tile independent; row bases are set per tile.
   const int lrow = lane >> 3, lslot = lane & 7;
-  int a_row_valid = 0;          // bit i: row i of this thread is < M
-  long a_base[4];               // dense: byte offset of row; conv: see below
-  int a_p0[4], a_p1[4];         // conv3x3: oy, ox ; convt3: t
-  int a_chunk[4];
+  int a_chunk[4], b_chunk[NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (w * 4 + i) * 8 + lrow;
-    const int m = m0 + r;
-    a_chunk[i] = lslot ^ ((r >> 1) & 7);
-    const bool ok = m < p.M;
-    a_row_valid |= ok ? (1 << i) : 0;
-    const int mm = ok ? m : 0;
-    if (AMODE == HI3D_A_DENSE) {
-      a_base[i] = (long)mm * p.lda * 2;
-      a_p0[i] = a_p1[i] = 0;
-    } else if (AMODE == HI3D_A_CONV3X3) {
-      const int hw = p.Hout * p.Wout;
-      const int f = mm / hw, rem = mm - f * hw;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_base[i] = (long)f * p.Hin * p.Win;       // pixel index of frame origin
-      a_p0[i] = oy * p.stride; a_p1[i] = ox * p.stride;
-    } else {
-      const int f = mm / p.HW;                    // frame index (b*T + t)
-      a_base[i] = (long)mm * p.Cin * 2;
-      a_p0[i] = f % p.T; a_p1[i] = 0;
-    }
-  }
-  long b_base[NT]; int b_chunk[NT]; int b_row_valid = 0;
+  for (int i = 0; i < 4; ++i) a_chunk[i] = lslot ^ ((((w * 4 + i) * 8 + lrow) >> 1) & 7);
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int j = (w * NT + i) * 8 + lrow;        // row of the W tile, 0..BN-1
     const int jw = j % (16 * NT);                  // row within its wave tile
     const int fi = (jw / (4 * NT)) * 4 + (jw & 3); // MFMA row index that reads it
     b_chunk[i] = lslot ^ ((fi >> 1) & 7);
-    const int n = n0 + j;
-    const bool ok = n < p.N;
-    b_row_valid |= ok ? (1 << i) : 0;
-    b_base[i] = (long)(ok ? n : 0) * p.K * 2;
   }
-
-  const char* zero = (const char*)hi3d_zero_page;
+  int a_row_valid = 0, b_row_valid = 0;
+  long a_base[4], b_base[NT];
+  int a_p0[4], a_p1[4];
   int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
 
+  auto setup = [&](int tile) {
+    const int m0 = (tile / p.nbn) * BM, n0 = (tile % p.nbn) * BN;
+    a_row_valid = 0; b_row_valid = 0; tap = 0; c0 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + (w * 4 + i) * 8 + lrow;
+      const bool ok = m < p.M;
+      a_row_valid |= ok ? (1 << i) : 0;
+      const int mm = ok ? m : 0;
+      if (AMODE == HI3D_A_DENSE) {
+        a_base[i] = (long)mm * p.lda * 2;
+        a_p0[i] = a_p1[i] = 0;
+      } else if (AMODE == HI3D_A_CONV3X3) {
+        const int hw = p.Hout * p.Wout;
+        const int f = mm / hw, rem = mm - f * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        a_base[i] = (long)f * p.Hin * p.Win;       // pixel index of frame origin
+        a_p0[i] = oy * p.stride; a_p1[i] = ox * p.stride;
+      } else {
+        const int f = mm / p.HW;                    // frame index (b*T + t)
+        a_base[i] = (long)mm * p.Cin * 2;
+        a_p0[i] = f % p.T; a_p1[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n0 + (w * NT + i) * 8 + lrow;
+      const bool ok = n < p.N;
+      b_row_valid |= ok ? (1 << i) : 0;
+      b_base[i] = (long)(ok ? n : 0) * p.K * 2;
+    }
+  };
+
+  const char* zero = (const char*)hi3d_zero_page;
   auto issue = [&](int kt, int st) {
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
@@ -148,81 +176,108 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     w_off[nt] = A_BYTES + (wn * 16 * NT + (fr >> 2) * 4 * NT + nt * 4 + (fr & 3)) * 128;
   const int w_sw = (fr >> 1) & 7;
 
-  f32x4 acc[4][NT];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int nk = p.K / BK;
+  // issue cursor runs one K-step ahead of the compute cursor, across tile boundaries:
+  // the first loads of tile t+1 are in flight while tile t runs its epilogue.
+  int i_tile = tile_begin, i_k = 0;
+  auto advance = [&]() {
+    if (++i_k == nk) { i_k = 0; ++i_tile; if (i_tile < tile_end) setup(i_tile); }
+  };
+  setup(i_tile);
   issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                      // stage st landed; stage st^1 free again
-    if (kt + 1 < nk) issue(kt + 1, st ^ 1);
-    const char* s = smem + st * STAGE;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      bf16x8 xf[4], wf[NT];
-      const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
-      const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nt] + cw);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-    }
-  }
+  advance();
+  int st = 0;
 
-  // ---- epilogue: lane (fg, fr) owns row m = .. + fr, columns nb .. nb + 4*NT - 1
-  const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int m0 = (tile / p.nbn) * BM, n0 = (tile % p.nbn) * BN;
+    f32x4 acc[4][NT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fr;
-    if (m >= p.M) continue;
-    const int grp = m / p.rpg;
-    const float s1 = p.a1 ? p.a1[grp] : 1.0f;
-    const float s2 = p.a2 ? p.a2[grp] : 1.0f;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nb + nt * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-        v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane (fg, fr) owns rows m = m0 + wm*64 + mt*16 + fr, columns nb .. nb + 4*NT - 1
+    const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
+    uint2 r1v[4][NT];
+
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                      // stage st landed; stage st^1 free again
+      if (i_tile < tile_end) { issue(i_k, st ^ 1); advance(); }
+      if (EPI == HI3D_EPI_AFFINE && kt == nk - 1 && p.R1) {
+        // residual tile: fetch under the last K-step's MFMAs instead of in the epilogue
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int m = m0 + wm * 64 + mt * 16 + fr;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = nb + nt * 4;
+            r1v[mt][nt] = (m < p.M && n < p.N) ? *(const uint2*)(p.R1 + (long)m * p.ldr1 + n) : make_uint2(0, 0);
+          }
+        }
       }
-      if (EPI == HI3D_EPI_GEGLU) {
-        const float o0 = v[0] * gelu_erf_f(v[2]);
-        const float o1 = v[1] * gelu_erf_f(v[3]);
-        unsigned int* o = (unsigned int*)((unsigned short*)p.out + (long)m * p.ldo + (n >> 1));
-        *o = pack_bf16x2(o0, o1);
-      } else {
-        if (p.rowvec) {
-          const f32x4 b = *(const f32x4*)(p.rowvec + (long)grp * p.ldrv + n);
+      const char* s = smem + st * STAGE;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        bf16x8 xf[4], wf[NT];
+        const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
+        const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nt] + cw);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+      }
+      st ^= 1;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + fr;
+      if (m >= p.M) continue;
+      const int grp = m / p.rpg;
+      const float s1 = p.a1 ? p.a1[grp] : 1.0f;
+      const float s2 = p.a2 ? p.a2[grp] : 1.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nb + nt * 4;
+        if (n >= p.N) continue;
+        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+        if (p.bias) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
           v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
-        if (p.R1) {
-          const uint2 r = *(const uint2*)(p.R1 + (long)m * p.ldr1 + n);
-          v[0] += bf16_to_f32(r.x & 0xffff); v[1] += bf16_to_f32(r.x >> 16);
-          v[2] += bf16_to_f32(r.y & 0xffff); v[3] += bf16_to_f32(r.y >> 16);
-        }
-        v[0] *= s1; v[1] *= s1; v[2] *= s1; v[3] *= s1;
-        if (p.R2) {
-          const uint2 r = *(const uint2*)(p.R2 + (long)m * p.ldr2 + n);
-          v[0] += s2 * bf16_to_f32(r.x & 0xffff); v[1] += s2 * bf16_to_f32(r.x >> 16);
-          v[2] += s2 * bf16_to_f32(r.y & 0xffff); v[3] += s2 * bf16_to_f32(r.y >> 16);
-        }
-        if (p.out_fp32) {
-          *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+        if (EPI == HI3D_EPI_GEGLU) {
+          const float o0 = v[0] * gelu_erf_f(v[2]);
+          const float o1 = v[1] * gelu_erf_f(v[3]);
+          unsigned int* o = (unsigned int*)((unsigned short*)p.out + (long)m * p.ldo + (n >> 1));
+          *o = pack_bf16x2(o0, o1);
         } else {
-          uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-          *(uint2*)((unsigned short*)p.out + (long)m * p.ldo + n) = o;
+          if (p.rowvec) {
+            const f32x4 b = *(const f32x4*)(p.rowvec + (long)grp * p.ldrv + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+          }
+          if (p.R1) {
+            const uint2 r = r1v[mt][nt];
+            v[0] += bf16_to_f32(r.x & 0xffff); v[1] += bf16_to_f32(r.x >> 16);
+            v[2] += bf16_to_f32(r.y & 0xffff); v[3] += bf16_to_f32(r.y >> 16);
+          }
+          v[0] *= s1; v[1] *= s1; v[2] *= s1; v[3] *= s1;
+          if (p.R2) {
+            const uint2 r = *(const uint2*)(p.R2 + (long)m * p.ldr2 + n);
+            v[0] += s2 * bf16_to_f32(r.x & 0xffff); v[1] += s2 * bf16_to_f32(r.x >> 16);
+            v[2] += s2 * bf16_to_f32(r.y & 0xffff); v[3] += s2 * bf16_to_f32(r.y >> 16);
+          }
+          if (p.out_fp32) {
+            *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)((unsigned short*)p.out + (long)m * p.ldo + n) = o;
+          }
         }
       }
     }
@@ -240,7 +295,9 @@ int launch(const GemmParams& p, hipStream_t stream) {
     if (e != hipSuccess) { hi3d_set_error(hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<NT, AMODE, EPI>), dim3(p.nbm * p.nbn), dim3(256), smem, stream, p);
+  const int tiles = p.nbm * p.nbn;
+  const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
+  hipLaunchKernelGGL((gemm_bf16_kernel<NT, AMODE, EPI>), dim3(grid), dim3(256), smem, stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int GN_PPB = 512;        // pixels per stats block
-constexpr int GN_APPLY_PPB = 128;  // pixels per apply block
+constexpr int GN_APPLY_PPB = 256;  // pixels per apply block
 
 __host__ __device__ inline int gn_threads(int C) {
   const int vec = C / 8;                       // 16-byte vectors per pixel
@@ -35,7 +35,24 @@ __global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__
   float s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-  for (int p = p_begin + rsub; p < p_end; p += rows_per_sweep) {
+  // 4 independent 16-byte loads in flight per thread (HBM latency hiding)
+  int p = p_begin + rsub;
+  for (; p + 3 * rows_per_sweep < p_end; p += 4 * rows_per_sweep) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = base[(long)(p + u * rows_per_sweep) * vec + chunk];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned int w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf16_to_f32(w[j] & 0xffff), b = bf16_to_f32(w[j] >> 16);
+        s[2 * j] += a; ss[2 * j] += a * a;
+        s[2 * j + 1] += b; ss[2 * j + 1] += b * b;
+      }
+    }
+  }
+  for (; p < p_end; p += rows_per_sweep) {
     const uint4 v = base[(long)p * vec + chunk];
     const unsigned int u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -100,9 +117,7 @@ __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
   }
   const int p_begin = blockIdx.x * GN_APPLY_PPB, p_end = min(P, p_begin + GN_APPLY_PPB);
   const long base = (long)inst * P * vec;
-  for (int p = p_begin + rsub; p < p_end; p += rows_per_sweep) {
-    const long idx = base + (long)p * vec + chunk;
-    const uint4 v = x[idx];
+  auto norm8 = [&](const uint4 v) {
     const unsigned int u[4] = {v.x, v.y, v.z, v.w};
     unsigned int o[4];
 #pragma unroll
@@ -112,7 +127,19 @@ __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
       if (SILU) { lo = silu_f(lo); hi = silu_f(hi); }
       o[j] = pack_bf16x2(lo, hi);
     }
-    y[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  int p = p_begin + rsub;
+  for (; p + 3 * rows_per_sweep < p_end; p += 4 * rows_per_sweep) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x[base + (long)(p + u * rows_per_sweep) * vec + chunk];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) y[base + (long)(p + u * rows_per_sweep) * vec + chunk] = norm8(v[u]);
+  }
+  for (; p < p_end; p += rows_per_sweep) {
+    const long idx = base + (long)p * vec + chunk;
+    y[idx] = norm8(x[idx]);
   }
 }
 
