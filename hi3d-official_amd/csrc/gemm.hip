@@ -24,7 +24,7 @@ struct GemmParams {
   const char* A; const char* W; const float* bias; const float* rowvec;
   const unsigned short* R1; const unsigned short* R2; const float* a1; const float* a2;
   void* out;
-  int M, N, K, lda, ldo, ldr1, ldr2, ldrv, rpg, out_fp32;
+  int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32;
   int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW;
   int nbm, nbn;
 };
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       const int n = n0 + (w * NT + i) * 8 + lrow;
       const bool ok = n < p.N;
       b_row_valid |= ok ? (1 << i) : 0;
-      b_base[i] = (long)(ok ? n : 0) * p.K * 2;
+      b_base[i] = (long)(ok ? n : 0) * p.ldw * 2;
     }
   };
 
@@ -330,7 +330,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.A = (const char*)d->A; p.W = (const char*)d->W; p.bias = d->bias; p.rowvec = d->rowvec;
   p.R1 = (const unsigned short*)d->R1; p.R2 = (const unsigned short*)d->R2; p.a1 = d->a1; p.a2 = d->a2;
   p.out = d->out; p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldo = d->ldo;
-  p.ldr1 = d->ldr1; p.ldr2 = d->ldr2; p.ldrv = d->ldrv > 0 ? d->ldrv : d->N; p.rpg = d->rows_per_group; p.out_fp32 = d->out_fp32;
+  p.ldr1 = d->ldr1; p.ldr2 = d->ldr2; p.ldrv = d->ldrv > 0 ? d->ldrv : d->N; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.rpg = d->rows_per_group; p.out_fp32 = d->out_fp32;
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW;
   if (d->amode == HI3D_A_DENSE) {
@@ -352,6 +352,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   }
   const int n_out = d->epi == HI3D_EPI_GEGLU ? d->N / 2 : d->N;
   if (d->ldo < n_out) HI3D_FAIL(HI3D_EINVAL, "gemm: ldo < N");
+  if (p.ldw < d->K || p.ldw % 8) HI3D_FAIL(HI3D_EALIGN, "gemm: ldw < K or ldw % 8 != 0");
   if (d->rowvec && (p.ldrv < d->N || p.ldrv % 4)) HI3D_FAIL(HI3D_EALIGN, "gemm: bad ldrv");
   if ((d->ldo % 4) || (d->R1 && d->ldr1 % 4) || (d->R2 && d->ldr2 % 4)) HI3D_FAIL(HI3D_EALIGN, "gemm: ld % 4 != 0");
   int tile = d->tile_n;

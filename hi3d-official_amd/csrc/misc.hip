@@ -94,6 +94,59 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restric
   y[idx] = x_is_f32 ? ((const float*)x)[src] : bf16_to_f32(((const unsigned short*)x)[src]);
 }
 
+__global__ void vae_latent_prepare_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                          const float* __restrict__ b, unsigned short* __restrict__ out,
+                                          int Cz, int HW, int Cpad, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;    // over N*HW pixels
+  if (idx >= total) return;
+  const int p = (int)(idx % HW); const long n = idx / HW;
+  float zi[8];
+  for (int c = 0; c < Cz; ++c) zi[c] = z[(n * Cz + c) * HW + p];
+  unsigned short* o = out + idx * Cpad;
+  for (int co = 0; co < Cz; ++co) {
+    float acc = b[co];
+    for (int ci = 0; ci < Cz; ++ci) acc += w[co * Cz + ci] * zi[ci];
+    o[co] = f32_to_bf16(acc);
+  }
+  for (int c = Cz; c < Cpad; ++c) o[c] = 0;
+}
+
+// one 256-thread block per row, the row (<= 16384 fp32) lives in registers
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, unsigned short* __restrict__ p,
+                                                          int N, int lds_, int ldp, float scale_log2) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* row = s + (long)blockIdx.x * lds_;
+  unsigned short* prow = p + (long)blockIdx.x * ldp;
+  float v[64];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int c = tid + i * 256;
+    v[i] = c < N ? row[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    v[i] = __builtin_amdgcn_exp2f((v[i] - mx) * scale_log2);     // exp2(-inf) = 0 for the padding
+    sum += v[i];
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wv] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int c = tid + i * 256;
+    if (c < ldp) prow[c] = f32_to_bf16(v[i] * inv);
+  }
+}
+
 inline unsigned grid_for(long n, int block, long cap = 65536) {
   long g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -181,6 +234,28 @@ extern "C" int hi3d_nhwc_to_nchw_f32(const void* x, float* y, int32_t N, int32_t
   const long total = (long)N * C * HW;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
                      x, y, C, HW, ldx, x_is_f32, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_vae_latent_prepare(const float* z, const float* w, const float* b, void* out,
+                                       int32_t N, int32_t Cz, int32_t HW, int32_t Cpad, void* stream) {
+  if (!z || !w || !b || !out) HI3D_FAIL(HI3D_EINVAL, "vae_latent_prepare: null pointer");
+  if (N <= 0 || HW <= 0 || Cz <= 0 || Cz > 8 || Cpad < Cz || Cpad % 8) HI3D_FAIL(HI3D_EINVAL, "vae_latent_prepare: bad size");
+  const long total = (long)N * HW;
+  hipLaunchKernelGGL(vae_latent_prepare_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     z, w, b, (unsigned short*)out, Cz, HW, Cpad, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_softmax_rows(const float* s, void* p, int32_t R, int32_t N, int32_t lds_, int32_t ldp,
+                                 float scale, void* stream) {
+  if (!s || !p) HI3D_FAIL(HI3D_EINVAL, "softmax_rows: null pointer");
+  if (R <= 0 || N <= 0 || lds_ < N || ldp < N) HI3D_FAIL(HI3D_EINVAL, "softmax_rows: bad size");
+  if (N > 16384 || ldp > 16384) HI3D_FAIL(HI3D_ESHAPE, "softmax_rows: rows longer than 16384 not supported");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, s, (unsigned short*)p, N, lds_, ldp,
+                     scale * 1.4426950408889634f);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

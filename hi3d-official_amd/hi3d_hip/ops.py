@@ -56,7 +56,7 @@ def _chk_dev(*ts):
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, conv3x3=None, convt3=None, tile_n=0):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
     """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
@@ -74,6 +74,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     d.ldr1 = R1.stride(-2) if R1 is not None else 0
     d.ldr2 = R2.stride(-2) if R2 is not None else 0
     d.ldrv = ldrv
+    d.ldw = ldw
     d.rows_per_group = rows_per_group
     d.epi = _l.EPI_GEGLU if geglu else _l.EPI_AFFINE
     d.out_fp32 = 1 if out_fp32 else 0
@@ -242,3 +243,24 @@ def tokens_to_nchw(x, N, Cc, H, W, ldx):
                                         1 if x.dtype == torch.float32 else 0, _stream()),
              "hi3d_nhwc_to_nchw_f32")
     return out
+
+
+def vae_latent_prepare(z, w, b, Cpad=64):
+    """z fp32 [N,Cz,h,w]; w fp32 [Cz,Cz]; b fp32 [Cz] -> bf16 [N*h*w, Cpad]."""
+    z = z.to(torch.float32).contiguous()
+    N, Cz, H, W = z.shape
+    out = torch.empty((N * H * W, Cpad), device=z.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_vae_latent_prepare(_p(z), _p(w), _p(b), _p(out), N, Cz, H * W, Cpad, _stream()),
+             "hi3d_vae_latent_prepare")
+    return out
+
+
+def softmax_rows(s, R, N, ldp, scale):
+    """s fp32 [R, N] -> bf16 [R, ldp] (columns >= N zero)."""
+    p = torch.empty((R, ldp), device=s.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_softmax_rows(_p(s), _p(p), R, N, s.stride(0), ldp, float(scale), _stream()), "hi3d_softmax_rows")
+    if prof:
+        prof.end("softmax_rows", 0.0, 4.0 * R * N + 2.0 * R * ldp, t0)
+    return p

@@ -1,0 +1,128 @@
+"""First-stage (AutoencoderKL) DECODER runtime on MI355X.
+
+Reference path: DiffusionEngine.decode_first_stage (sgm/models/diffusion.py:117-135) ->
+AutoencodingEngineLegacy.decode (sgm/models/autoencoder.py:490-505, post_quant_conv) ->
+Decoder.forward (sgm/modules/diffusionmodules/model.py:715-748).
+
+Same design as the UNet runtime: channels-last bf16 frames [N, H*W, C], every 3x3 conv is
+the implicit-GEMM MFMA kernel (nearest-2x upsample folded into its gather, residual add in
+its epilogue), GroupNorm(eps 1e-6)+swish is one fused pass.  The mid-block attention is a
+single 512-wide head over up to 16384 tokens; it is run un-fused -- S = q k^T (GEMM, fp32
+scores), row softmax, O = P V (GEMM) -- because with 288 GB of HBM the 1 GiB score matrix
+of one 1024x1024 frame is affordable and both products then run on the tuned GEMM kernel.
+Frames are independent: decode() can be called on any slice of the clip (frame sharding
+across GPUs, all-gather of the decoded frames afterwards).
+"""
+import torch
+
+from . import ops, pack
+
+CZ_PAD = 64
+
+
+class VAEDecoderRuntime:
+    def __init__(self, state_dict, ddconfig, device, prefix=""):
+        self.dd, self.dev = dict(ddconfig), torch.device(device)
+        dd = self.dd
+        self.ch, self.mult, self.nres = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+        if self.ch % 64:
+            raise ops._l.Hi3dError("VAE decoder runtime needs ch % 64 == 0 (Hi3D uses ch=128)")
+        if dd["z_channels"] > 8:
+            raise ops._l.Hi3dError("z_channels > 8 not supported")
+        self._pack(state_dict, prefix)
+
+    def _pack(self, sd, P):
+        dev = self.dev
+        g = lambda k: sd[P + k].detach().to(dev)
+        f32 = lambda k: pack.f32(g(k))
+        W = {}
+        zc = self.dd["z_channels"]
+        W["pq.w"] = f32("post_quant_conv.weight").reshape(zc, -1).contiguous()
+        W["pq.b"] = f32("post_quant_conv.bias")
+        D = "decoder."
+        W["conv_in.w"] = pack.pack_conv3x3(g(D + "conv_in.weight"), cin_pad=CZ_PAD); W["conv_in.b"] = f32(D + "conv_in.bias")
+
+        def resnet(p):
+            for n in ("norm1", "norm2"):
+                W[f"{p}.{n}.g"] = f32(f"{D}{p}.{n}.weight"); W[f"{p}.{n}.b"] = f32(f"{D}{p}.{n}.bias")
+            for n in ("conv1", "conv2"):
+                W[f"{p}.{n}.w"] = pack.pack_conv3x3(g(f"{D}{p}.{n}.weight")); W[f"{p}.{n}.b"] = f32(f"{D}{p}.{n}.bias")
+            if (P + D + p + ".nin_shortcut.weight") in sd:
+                W[p + ".nin.w"] = pack.pack_conv1x1(g(f"{D}{p}.nin_shortcut.weight")); W[p + ".nin.b"] = f32(f"{D}{p}.nin_shortcut.bias")
+
+        resnet("mid.block_1"); resnet("mid.block_2")
+        a = "mid.attn_1"
+        W[a + ".norm.g"] = f32(D + a + ".norm.weight"); W[a + ".norm.b"] = f32(D + a + ".norm.bias")
+        W[a + ".qkv.w"] = pack._bf16(torch.cat([pack.pack_conv1x1(g(f"{D}{a}.{n}.weight")) for n in ("q", "k", "v")], 0))
+        W[a + ".qkv.b"] = torch.cat([f32(f"{D}{a}.{n}.bias") for n in ("q", "k", "v")]).contiguous()
+        W[a + ".o.w"] = pack.pack_conv1x1(g(D + a + ".proj_out.weight")); W[a + ".o.b"] = f32(D + a + ".proj_out.bias")
+        for lvl in range(len(self.mult)):
+            for b in range(self.nres + 1):
+                resnet(f"up.{lvl}.block.{b}")
+            if lvl != 0:
+                W[f"up.{lvl}.up.w"] = pack.pack_conv3x3(g(f"{D}up.{lvl}.upsample.conv.weight"))
+                W[f"up.{lvl}.up.b"] = f32(f"{D}up.{lvl}.upsample.conv.bias")
+        W["norm_out.g"] = f32(D + "norm_out.weight"); W["norm_out.b"] = f32(D + "norm_out.bias")
+        self.out_ch = self.dd["out_ch"]
+        ocp = (self.out_ch + 3) // 4 * 4
+        W["conv_out.w"] = pack.pack_conv3x3(g(D + "conv_out.weight"), cout_pad=ocp)
+        W["conv_out.b"] = pack.pad_vec(g(D + "conv_out.bias"), ocp)
+        self.W = W
+
+    # ------------------------------------------------------------------
+    def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False):
+        Ho, Wo = (2 * H, 2 * Wd) if up else (H, Wd)
+        return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
+                        out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up))
+
+    def _resnet(self, p, x, N, H, Wd, Cin, Cout):
+        W, HW = self.W, H * Wd
+        h = ops.groupnorm_silu(x, W[p + ".norm1.g"], W[p + ".norm1.b"], N, HW, Cin, 1e-6)
+        h = self._conv(h, p + ".conv1", N, H, Wd, Cin, Cout)
+        h = ops.groupnorm_silu(h, W[p + ".norm2.g"], W[p + ".norm2.b"], N, HW, Cout, 1e-6)
+        skip = x
+        if (p + ".nin.w") in W:
+            skip = ops.gemm(x, W[p + ".nin.w"], M=N * HW, N=Cout, K=Cin, bias=W[p + ".nin.b"])
+        return self._conv(h, p + ".conv2", N, H, Wd, Cout, Cout, R1=skip)
+
+    def _attn(self, p, x, N, S, C):
+        W = self.W
+        if C % 64:
+            raise ops._l.Hi3dError("attention width must be a multiple of 64")
+        n = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], N, S, C, 1e-6, silu=False)
+        qkv = ops.gemm(n, W[p + ".qkv.w"], M=N * S, N=3 * C, K=C, bias=W[p + ".qkv.b"])
+        vt = ops.transpose_v(qkv[:, 2 * C:], N, C // 64, S, 3 * C)          # [N, C/64, 64, S_pad] == V^T [N][C][S_pad]
+        S_pad = vt.shape[-1]
+        o = torch.empty((N * S, C), device=x.device, dtype=torch.bfloat16)
+        for f in range(N):                                                   # one frame's score matrix at a time
+            q = qkv[f * S:(f + 1) * S]
+            k = q[:, C:]
+            sc = ops.gemm(q, k, M=S, N=S, K=C, lda=3 * C, ldw=3 * C, out_fp32=True)     # [S, S] fp32
+            pr = ops.softmax_rows(sc, S, S, S_pad, float(C) ** -0.5)
+            ops.gemm(pr, vt[f], M=S, N=C, K=S_pad, lda=S_pad, ldw=S_pad, out=o[f * S:(f + 1) * S])
+        return ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x)
+
+    @torch.no_grad()
+    def decode(self, z):
+        """z: [N, Cz, h, w] latents already divided by scale_factor -> fp32 [N, out_ch, 8h, 8w]."""
+        W = self.W
+        N, _, H, Wd = z.shape
+        top = self.ch * self.mult[-1]
+        h = ops.vae_latent_prepare(z.to(self.dev), W["pq.w"], W["pq.b"], CZ_PAD)
+        h = self._conv(h, "conv_in", N, H, Wd, CZ_PAD, top)
+        h = self._resnet("mid.block_1", h, N, H, Wd, top, top)
+        h = self._attn("mid.attn_1", h, N, H * Wd, top)
+        h = self._resnet("mid.block_2", h, N, H, Wd, top, top)
+        cin = top
+        for lvl in reversed(range(len(self.mult))):
+            cout = self.ch * self.mult[lvl]
+            for b in range(self.nres + 1):
+                h = self._resnet(f"up.{lvl}.block.{b}", h, N, H, Wd, cin, cout)
+                cin = cout
+            if lvl != 0:
+                h = self._conv(h, f"up.{lvl}.up", N, H, Wd, cout, cout, up=1)
+                H, Wd = 2 * H, 2 * Wd
+        h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6)
+        ocp = W["conv_out.b"].numel()
+        out = self._conv(h, "conv_out", N, H, Wd, cin, ocp, out_fp32=True)
+        return ops.tokens_to_nchw(out, N, self.out_ch, H, Wd, ocp)

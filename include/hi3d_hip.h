@@ -90,6 +90,7 @@ typedef struct hi3d_gemm_desc {
   int32_t M, N, K;
   int32_t lda, ldo, ldr1, ldr2;  /* in elements                               */
   int32_t ldrv;                  /* row stride of rowvec (0 = N)              */
+  int32_t ldw;                   /* row stride of W in elements (0 = K)       */
   int32_t rows_per_group;        /* >=1                                       */
   int32_t amode, epi, out_fp32;
   /* conv3x3: */
@@ -205,6 +206,24 @@ int hi3d_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, in
                                int32_t Cpad, void* stream);
 int hi3d_nhwc_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t HW,
                           int32_t ldx, int32_t x_is_f32, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* First-stage (VAE) decoder helpers                                         */
+/* ------------------------------------------------------------------------ */
+/* post_quant_conv (1x1, Cz -> Cz, sgm/models/autoencoder.py:490-505) fused with the
+ * NCHW fp32 -> channels-last bf16 conversion:
+ *   out[n][p][co] = sum_ci w[co][ci] * z[n][ci][p] + b[co]   co < Cz ; 0 for co >= Cz
+ * Cz <= 8, Cpad % 8 == 0.                                                    */
+int hi3d_vae_latent_prepare(const float* z, const float* w, const float* b, void* out,
+                            int32_t N, int32_t Cz, int32_t HW, int32_t Cpad, void* stream);
+
+/* Row softmax of fp32 scores into bf16 probabilities (the VAE mid-block attention,
+ * sgm/modules/diffusionmodules/model.py:180-195, single head d = C = 512, is run as
+ * GEMM(q k^T) -> this -> GEMM(p v)):
+ *   p[r][c] = exp(scale*(s[r][c] - max_c s[r])) / sum_c(...)  for c < N ; 0 for N <= c < ldp
+ * N <= 16384.                                                                */
+int hi3d_softmax_rows(const float* s, void* p, int32_t R, int32_t N, int32_t lds,
+                      int32_t ldp, float scale, void* stream);
 
 #ifdef __cplusplus
 }

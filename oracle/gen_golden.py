@@ -167,7 +167,7 @@ def main():
                                                max_scale=2.5, stage=1),
         "sampler_tiny_s2": lambda: gen_sampler("sampler_tiny_s2", unet_cfg(2, 64), T=4, hw=8, steps=4,
                                                max_scale=2.0, stage=2, iseed=5),
-        "vae_tiny": lambda: gen_vae("vae_tiny", 32, 2, 8),
+        "vae_tiny": lambda: gen_vae("vae_tiny", 64, 2, 8),
         "vae_full_lat8": lambda: gen_vae("vae_full_lat8", 128, 1, 8, iseed=2),
         "unet_s1_lat16": lambda: gen_unet("unet_s1_lat16", unet_cfg(1), T=4, hw=16, iseed=1),
         "unet_s2_lat16": lambda: gen_unet("unet_s2_lat16", unet_cfg(2), T=4, hw=16, iseed=2),

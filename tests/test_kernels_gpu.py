@@ -240,3 +240,20 @@ def test_errors_are_loud(dev):
         ops.gemm(A, W, M=64, N=64, K=72)
     with pytest.raises(Hi3dError, match="CPU tensor"):
         ops.gemm(A.cpu(), W, M=64, N=64, K=64)
+
+
+def test_vae_helpers(dev):
+    from hi3d_hip import ops
+    z = rnd((2, 4, 5, 6), 1)
+    w, b = rnd((4, 4), 2), rnd((4,), 3)
+    ref = torch.zeros(2, 30, 64)
+    ref[:, :, :4] = (torch.einsum("oc,nchw->nohw", w, z) + b[None, :, None, None]).reshape(2, 4, 30).permute(0, 2, 1)
+    out = ops.vae_latent_prepare(z.to(dev), w.to(dev), b.to(dev), 64)
+    assert relerr(out.reshape(2, 30, 64), ref) < 5e-3
+    s = rnd((7, 1000), 4) * 3
+    p = ops.softmax_rows(s.to(dev), 7, 1000, 1024, 0.3)
+    assert relerr(p[:, :1000], torch.softmax(s * 0.3, -1)) < 5e-3 and p[:, 1000:].float().abs().sum().item() == 0.0
+    # GEMM with strided W (ldw): scores = q k^T straight out of a fused qkv buffer
+    qkv = bf(rnd((300, 3 * 128), 5))
+    sc = ops.gemm(qkv.to(dev), qkv.to(dev)[:, 128:], M=300, N=300, K=128, lda=384, ldw=384, out_fp32=True)
+    assert relerr(sc, qkv[:, :128].float() @ qkv[:, 128:256].float().T) < 1e-5
