@@ -24,110 +24,94 @@ struct GemmParams {
   const char* A; const char* W; const float* bias; const float* rowvec;
   const unsigned short* R1; const unsigned short* R2; const float* a1; const float* a2;
   void* out;
-  int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32;
+  int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8, dbg;
   int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW;
   int nbm, nbn;
 };
 
-constexpr int BM = 128, BK = 64;
+constexpr int BK = 64;
 
-// The kernel can walk a contiguous range of tiles per block (persistent form, next tile's
-// loads in flight during the epilogue).  On MI355X the dynamic one-block-per-tile dispatch
-// measured faster (hardware staggers co-resident blocks; persistent blocks run in lockstep),
-// so the default grid is one block per tile; HI3D_GEMM_BLOCKS_PER_CU=k selects k*CUs blocks.
-int persistent_grid() {
-  static int g = 0;
-  if (g == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    const char* e = getenv("HI3D_GEMM_BLOCKS_PER_CU");   // tuning knob (0 = one block per tile)
-    const int per_cu = e ? atoi(e) : 0;   // measured: one block per tile beats the persistent range at every Hi3D shape
-    g = per_cu > 0 ? per_cu * cus : 0x7fffffff;
-  }
-  return g;
-}
-
-template <int NT, int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
-  constexpr int BN = 32 * NT;
-  constexpr int A_BYTES = BM * BK * 2;      // 16 KiB
-  constexpr int B_BYTES = BN * BK * 2;      // 16 / 20 KiB
+// WM   : waves along M (2 -> 128-row tile, 4 waves; 4 -> 256-row tile, 8 waves); 2 waves along N
+// NT   : 16-column MFMA tiles per wave along N (4 -> BN = 128, 5 -> BN = 160)
+// NS   : LDS ring stages.  NS = 2: loads of K-step k+1 fly during K-step k (vmcnt(0) per step).
+//        NS = 3: two K-steps in flight, counted vmcnt (the newest stage's LDS-DMA stays in
+//        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
+template <int WM, int NT, int NS, int AMODE, int EPI>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int NW = WM * 2;                 // waves per block
+  constexpr int BM = WM * 64, BN = 32 * NT;
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = BM / 8 / NW;                  // 1 KiB LDS-DMA pieces per wave: always 4
+  constexpr int W_PIECES = (4 * NT + NW - 1) / NW;       // per wave, upper bound (piece q = w + NW*i < 4*NT)
+  constexpr int LPS_MIN = A_PIECES + (4 * NT) / NW;      // fewest LDS-DMA ops any wave issues per stage
+  static_assert(A_PIECES == 4, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
 
-  // ---- persistent block: a contiguous range of output tiles (n fastest, so consecutive
-  // tiles re-read the same activation rows from L2).  Blocks are renumbered XCD-aware
-  // (bijective for any grid) so that neighbouring ranges share one XCD's L2.
-  const int tiles_total = p.nbm * p.nbn;
-  const int nblk = gridDim.x;
+  // ---- block -> tile, XCD-aware: consecutive logical ids (which share the A tile
+  // and sweep W) stay on one XCD's L2.  Bijective for any grid size.
+  const int nblk = p.nbm * p.nbn;
   int lid;
   {
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tpb = (tiles_total + nblk - 1) / nblk;
-  const int tile_begin = lid * tpb;
-  const int tile_end = min(tiles_total, tile_begin + tpb);
-  if (tile_begin >= tile_end) return;
+  const int tn = lid % p.nbn, tm = lid / p.nbn;
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
   // (r&7 within an 8-row, 1 KiB DMA piece); lane slot s carries source chunk
-  // s ^ swz(r).  Chunk assignment is tile independent; row bases are set per tile.
+  // s ^ swz(r).
   const int lrow = lane >> 3, lslot = lane & 7;
-  int a_chunk[4], b_chunk[NT];
+  int a_row_valid = 0;          // bit i: row i of this thread is < M
+  long a_base[4];               // dense: byte offset of row; conv: see below
+  int a_p0[4], a_p1[4];         // conv3x3: oy, ox ; convt3: t
+  int a_chunk[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_chunk[i] = lslot ^ ((((w * 4 + i) * 8 + lrow) >> 1) & 7);
+  for (int i = 0; i < 4; ++i) {
+    const int r = (w * 4 + i) * 8 + lrow;
+    const int m = m0 + r;
+    a_chunk[i] = lslot ^ ((r >> 1) & 7);
+    const bool ok = m < p.M;
+    a_row_valid |= ok ? (1 << i) : 0;
+    const int mm = ok ? m : 0;
+    if (AMODE == HI3D_A_DENSE) {
+      a_base[i] = (long)mm * p.lda * 2;
+      a_p0[i] = a_p1[i] = 0;
+    } else if (AMODE == HI3D_A_CONV3X3) {
+      const int hw = p.Hout * p.Wout;
+      const int f = mm / hw, rem = mm - f * hw;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_base[i] = (long)f * p.Hin * p.Win;       // pixel index of frame origin
+      a_p0[i] = oy * p.stride; a_p1[i] = ox * p.stride;
+    } else {
+      const int f = mm / p.HW;                    // frame index (b*T + t)
+      a_base[i] = (long)mm * p.Cin * 2;
+      a_p0[i] = f % p.T; a_p1[i] = 0;
+    }
+  }
+  long b_base[W_PIECES]; int b_chunk[W_PIECES]; int b_row_valid = 0;
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int j = (w * NT + i) * 8 + lrow;        // row of the W tile, 0..BN-1
+  for (int i = 0; i < W_PIECES; ++i) {
+    const int q = w + NW * i;                      // W piece (8 rows) handled by this wave
+    const int j = q * 8 + lrow;                    // row of the W tile, 0..BN-1
     const int jw = j % (16 * NT);                  // row within its wave tile
     const int fi = (jw / (4 * NT)) * 4 + (jw & 3); // MFMA row index that reads it
     b_chunk[i] = lslot ^ ((fi >> 1) & 7);
+    const int n = n0 + j;
+    const bool ok = n < p.N && q < 4 * NT;
+    b_row_valid |= ok ? (1 << i) : 0;
+    b_base[i] = (long)(ok ? n : 0) * p.ldw * 2;
   }
-  int a_row_valid = 0, b_row_valid = 0;
-  long a_base[4], b_base[NT];
-  int a_p0[4], a_p1[4];
-  int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
-
-  auto setup = [&](int tile) {
-    const int m0 = (tile / p.nbn) * BM, n0 = (tile % p.nbn) * BN;
-    a_row_valid = 0; b_row_valid = 0; tap = 0; c0 = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + (w * 4 + i) * 8 + lrow;
-      const bool ok = m < p.M;
-      a_row_valid |= ok ? (1 << i) : 0;
-      const int mm = ok ? m : 0;
-      if (AMODE == HI3D_A_DENSE) {
-        a_base[i] = (long)mm * p.lda * 2;
-        a_p0[i] = a_p1[i] = 0;
-      } else if (AMODE == HI3D_A_CONV3X3) {
-        const int hw = p.Hout * p.Wout;
-        const int f = mm / hw, rem = mm - f * hw;
-        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        a_base[i] = (long)f * p.Hin * p.Win;       // pixel index of frame origin
-        a_p0[i] = oy * p.stride; a_p1[i] = ox * p.stride;
-      } else {
-        const int f = mm / p.HW;                    // frame index (b*T + t)
-        a_base[i] = (long)mm * p.Cin * 2;
-        a_p0[i] = f % p.T; a_p1[i] = 0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = n0 + (w * NT + i) * 8 + lrow;
-      const bool ok = n < p.N;
-      b_row_valid |= ok ? (1 << i) : 0;
-      b_base[i] = (long)(ok ? n : 0) * p.ldw * 2;
-    }
-  };
 
   const char* zero = (const char*)hi3d_zero_page;
+  int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
+
   auto issue = [&](int kt, int st) {
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
@@ -154,12 +138,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         ok = ok && tt >= 0 && tt < p.T;
         src = p.A + a_base[i] + ((long)(tap - 1) * p.HW * p.Cin + c0 + a_chunk[i] * 8) * 2;
       }
+      if (p.dbg & 1) ok = false;   // timing experiment only (HI3D_GEMM_DEBUG)
       lds_dma16(ok ? src : zero, sA + (w * 4 + i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const char* src = p.W + b_base[i] + (long)(k0 + b_chunk[i] * 8) * 2;
-      lds_dma16(((b_row_valid >> i) & 1) ? src : zero, sB + (w * NT + i) * 1024);
+    for (int i = 0; i < W_PIECES; ++i) {
+      const int q = w + NW * i;
+      if (q < 4 * NT) {                           // wave-uniform
+        const char* src = p.W + b_base[i] + (long)(k0 + b_chunk[i] * 8) * 2;
+        lds_dma16((((b_row_valid >> i) & 1) && !(p.dbg & 2)) ? src : zero, sB + q * 1024);
+      }
     }
     if (AMODE != HI3D_A_DENSE) { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
   };
@@ -176,142 +164,166 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     w_off[nt] = A_BYTES + (wn * 16 * NT + (fr >> 2) * 4 * NT + nt * 4 + (fr & 3)) * 128;
   const int w_sw = (fr >> 1) & 7;
 
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // lane (fg, fr) owns rows m = m0 + wm*64 + mt*16 + fr, columns nb .. nb + 4*NT - 1
+  const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
+
   const int nk = p.K / BK;
-  // issue cursor runs one K-step ahead of the compute cursor, across tile boundaries:
-  // the first loads of tile t+1 are in flight while tile t runs its epilogue.
-  int i_tile = tile_begin, i_k = 0;
-  auto advance = [&]() {
-    if (++i_k == nk) { i_k = 0; ++i_tile; if (i_tile < tile_end) setup(i_tile); }
-  };
-  setup(i_tile);
   issue(0, 0);
-  advance();
+  if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;
-
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
-    const int m0 = (tile / p.nbn) * BM, n0 = (tile % p.nbn) * BN;
-    f32x4 acc[4][NT];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // lane (fg, fr) owns rows m = m0 + wm*64 + mt*16 + fr, columns nb .. nb + 4*NT - 1
-    const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
-    uint2 r1v[4][NT];
-
-    for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NS == 3) {
+      // stage kt must have landed; the LDS-DMA of stage kt+1 (>= LPS_MIN ops per wave) may stay in flight
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS_MIN) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();           // raw barrier: no implicit vmcnt(0) drain
+      if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                      // stage st landed; stage st^1 free again
-      if (i_tile < tile_end) { issue(i_k, st ^ 1); advance(); }
-      if (EPI == HI3D_EPI_AFFINE && kt == nk - 1 && p.R1) {
-        // residual tile: fetch under the last K-step's MFMAs instead of in the epilogue
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int m = m0 + wm * 64 + mt * 16 + fr;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int n = nb + nt * 4;
-            r1v[mt][nt] = (m < p.M && n < p.N) ? *(const uint2*)(p.R1 + (long)m * p.ldr1 + n) : make_uint2(0, 0);
-          }
-        }
-      }
-      const char* s = smem + st * STAGE;
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        bf16x8 xf[4], wf[NT];
-        const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
-        const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nt] + cw);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-      }
-      st ^= 1;
+      __syncthreads();                        // stage st landed; stage st^1 free again
+      if (kt + 1 < nk) issue(kt + 1, st ^ 1);
     }
-
-    // ---- epilogue
+    const char* s = smem + st * STAGE;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + fr;
-      if (m >= p.M) continue;
-      const int grp = m / p.rpg;
-      const float s1 = p.a1 ? p.a1[grp] : 1.0f;
-      const float s2 = p.a2 ? p.a2[grp] : 1.0f;
+    for (int kh = 0; kh < 2; ++kh) {
+      bf16x8 xf[4], wf[NT];
+      const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
+      const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nt] + cw);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    if (NS == 3) st = (st == 2) ? 0 : st + 1;
+    else st ^= 1;
+  }
+
+  // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
+  // directly that is 64 scattered 8-byte requests per instruction, and the L2 request rate --
+  // not bandwidth -- bounds every short-K GEMM.  So the fp32 tile goes through LDS (the
+  // ring is free now), two half-tiles of BM/2 rows, and all global traffic (residual loads,
+  // stores) is issued row-contiguous, 16 bytes per lane.
+  constexpr int BN_OUT = (EPI == HI3D_EPI_GEGLU) ? BN / 2 : BN;
+  constexpr int LROW = BN_OUT * 4 + 16;            // bytes; +16 spreads ds_write_b128 lanes over banks
+  constexpr int HR = BM / 2;                       // rows per half tile
+  constexpr int CPR = BN_OUT / 8;                  // 8-column chunks per row
+  constexpr int NTHR = NW * 64;
+  const int n0_out = (EPI == HI3D_EPI_GEGLU) ? n0 / 2 : n0;
+  const int N_out = (EPI == HI3D_EPI_GEGLU) ? p.N / 2 : p.N;
+  __syncthreads();                                 // every wave is done with the operand ring
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      const int mt = half * 2 + mh;
+      char* trow = smem + (wm * 32 + mh * 16 + fr) * LROW;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int n = nb + nt * 4;
-        if (n >= p.N) continue;
-        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-        if (p.bias) {
+        const int cl = wn * 16 * NT + fg * 4 * NT + nt * 4;    // tile-local column of acc[mt][nt][0]
+        const int n = n0 + cl;
+        f32x4 v = acc[mt][nt];
+        if (p.bias && n < p.N) {
           const f32x4 b = *(const f32x4*)(p.bias + n);
           v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
         if (EPI == HI3D_EPI_GEGLU) {
-          const float o0 = v[0] * gelu_erf_f(v[2]);
-          const float o1 = v[1] * gelu_erf_f(v[3]);
-          unsigned int* o = (unsigned int*)((unsigned short*)p.out + (long)m * p.ldo + (n >> 1));
-          *o = pack_bf16x2(o0, o1);
+          float2 o; o.x = v[0] * gelu_erf_f(v[2]); o.y = v[1] * gelu_erf_f(v[3]);
+          *(float2*)(trow + (cl >> 1) * 4) = o;
         } else {
-          if (p.rowvec) {
-            const f32x4 b = *(const f32x4*)(p.rowvec + (long)grp * p.ldrv + n);
-            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-          }
-          if (p.R1) {
-            const uint2 r = r1v[mt][nt];
-            v[0] += bf16_to_f32(r.x & 0xffff); v[1] += bf16_to_f32(r.x >> 16);
-            v[2] += bf16_to_f32(r.y & 0xffff); v[3] += bf16_to_f32(r.y >> 16);
-          }
-          v[0] *= s1; v[1] *= s1; v[2] *= s1; v[3] *= s1;
-          if (p.R2) {
-            const uint2 r = *(const uint2*)(p.R2 + (long)m * p.ldr2 + n);
-            v[0] += s2 * bf16_to_f32(r.x & 0xffff); v[1] += s2 * bf16_to_f32(r.x >> 16);
-            v[2] += s2 * bf16_to_f32(r.y & 0xffff); v[3] += s2 * bf16_to_f32(r.y >> 16);
-          }
-          if (p.out_fp32) {
-            *(f32x4*)((float*)p.out + (long)m * p.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
-          } else {
-            uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            *(uint2*)((unsigned short*)p.out + (long)m * p.ldo + n) = o;
-          }
+          *(f32x4*)(trow + cl * 4) = v;
         }
       }
     }
+    __syncthreads();
+    for (int c = tid; c < HR * CPR; c += NTHR) {
+      const int lr = c / CPR, c8 = c - lr * CPR;
+      const int m = m0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+      const int n = n0_out + c8 * 8;
+      if (m >= p.M || n >= N_out || (p.dbg & 4)) continue;
+      const char* tp = smem + lr * LROW + c8 * 32;
+      const f32x4 lo = *(const f32x4*)tp, hi = *(const f32x4*)(tp + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bool full = (n + 8 <= N_out) && p.vec8;          // else: only the first 4 columns exist / are aligned
+      if (EPI == HI3D_EPI_AFFINE) {
+        const int grp = m / p.rpg;
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (long)grp * p.ldrv + n;
+          const f32x4 r0 = *(const f32x4*)rv;
+          v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+          if (n + 8 <= N_out) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
+        }
+        if (p.R1) {
+          const unsigned short* rp = p.R1 + (long)m * p.ldr1 + n;
+          uint4 r;
+          if (full) r = *(const uint4*)rp; else { const uint2 t = *(const uint2*)rp; r = make_uint4(t.x, t.y, 0, 0); if (n + 8 <= N_out) { const uint2 u = *(const uint2*)(rp + 4); r.z = u.x; r.w = u.y; } }
+          v[0] += bf16_to_f32(r.x & 0xffff); v[1] += bf16_to_f32(r.x >> 16); v[2] += bf16_to_f32(r.y & 0xffff); v[3] += bf16_to_f32(r.y >> 16);
+          v[4] += bf16_to_f32(r.z & 0xffff); v[5] += bf16_to_f32(r.z >> 16); v[6] += bf16_to_f32(r.w & 0xffff); v[7] += bf16_to_f32(r.w >> 16);
+        }
+        if (p.a1) { const float s1 = p.a1[grp];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= s1; }
+        if (p.R2) {
+          const float s2 = p.a2 ? p.a2[grp] : 1.0f;
+          const unsigned short* rp = p.R2 + (long)m * p.ldr2 + n;
+          uint4 r;
+          if (full) r = *(const uint4*)rp; else { const uint2 t = *(const uint2*)rp; r = make_uint4(t.x, t.y, 0, 0); if (n + 8 <= N_out) { const uint2 u = *(const uint2*)(rp + 4); r.z = u.x; r.w = u.y; } }
+          v[0] += s2 * bf16_to_f32(r.x & 0xffff); v[1] += s2 * bf16_to_f32(r.x >> 16); v[2] += s2 * bf16_to_f32(r.y & 0xffff); v[3] += s2 * bf16_to_f32(r.y >> 16);
+          v[4] += s2 * bf16_to_f32(r.z & 0xffff); v[5] += s2 * bf16_to_f32(r.z >> 16); v[6] += s2 * bf16_to_f32(r.w & 0xffff); v[7] += s2 * bf16_to_f32(r.w >> 16);
+        }
+      }
+      if (p.out_fp32) {
+        float* op = (float*)p.out + (long)m * p.ldo + n;
+        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+        if (n + 8 <= N_out) *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        unsigned short* op = (unsigned short*)p.out + (long)m * p.ldo + n;
+        if (full) {
+          *(uint4*)op = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          *(uint2*)op = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          if (n + 8 <= N_out) *(uint2*)(op + 4) = make_uint2(pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+      }
+    }
+    if (half == 0) __syncthreads();
   }
 }
 
-template <int NT, int AMODE, int EPI>
+template <int WM, int NT, int NS, int AMODE, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
-  constexpr int BN = 32 * NT;
-  constexpr int smem = 2 * (BM * BK * 2 + BN * BK * 2);
+  constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2);
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<NT, AMODE, EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) { hi3d_set_error(hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  const int tiles = p.nbm * p.nbn;
-  const int grid = tiles < persistent_grid() ? tiles : persistent_grid();
-  hipLaunchKernelGGL((gemm_bf16_kernel<NT, AMODE, EPI>), dim3(grid), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>), dim3(p.nbm * p.nbn), dim3(WM * 128), smem, stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }
 
-template <int NT>
+template <int WM, int NT, int NS>
 int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
   if (epi == HI3D_EPI_GEGLU) {
     if (amode != HI3D_A_DENSE) HI3D_FAIL(HI3D_ESHAPE, "gemm: GEGLU epilogue only with dense A");
-    return launch<NT, HI3D_A_DENSE, HI3D_EPI_GEGLU>(p, s);
+    return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_GEGLU>(p, s);
   }
   switch (amode) {
-    case HI3D_A_DENSE: return launch<NT, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
-    case HI3D_A_CONV3X3: return launch<NT, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
-    case HI3D_A_CONVT3: return launch<NT, HI3D_A_CONVT3, HI3D_EPI_AFFINE>(p, s);
+    case HI3D_A_DENSE: return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
+    case HI3D_A_CONV3X3: return launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
+    case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE>(p, s);
   }
   HI3D_FAIL(HI3D_EINVAL, "gemm: bad amode");
 }
@@ -355,15 +367,32 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (p.ldw < d->K || p.ldw % 8) HI3D_FAIL(HI3D_EALIGN, "gemm: ldw < K or ldw % 8 != 0");
   if (d->rowvec && (p.ldrv < d->N || p.ldrv % 4)) HI3D_FAIL(HI3D_EALIGN, "gemm: bad ldrv");
   if ((d->ldo % 4) || (d->R1 && d->ldr1 % 4) || (d->R2 && d->ldr2 % 4)) HI3D_FAIL(HI3D_EALIGN, "gemm: ld % 4 != 0");
+  // 16-byte epilogue I/O needs 8-element alignment of every row; otherwise 8-byte pieces
+  p.vec8 = (d->ldo % 8 == 0) && (!d->R1 || d->ldr1 % 8 == 0) && (!d->R2 || d->ldr2 % 8 == 0) &&
+           (((uintptr_t)d->out | (uintptr_t)d->R1 | (uintptr_t)d->R2) % 16 == 0);
+  p.dbg = 0;
+  if (const char* e = getenv("HI3D_GEMM_DEBUG")) p.dbg = atoi(e);
   int tile = d->tile_n;
   if (tile == 0) {
     // 160 suits every multiple of 320; otherwise pick the tile that wastes fewer columns
     const int w128 = (d->N + 127) / 128 * 128, w160 = (d->N + 159) / 160 * 160;
-    tile = (w160 < w128) ? 160 : 128;
+    tile = (w160 <= w128) ? 160 : 128;
+    if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile = t; }
   }
   if (tile != 128 && tile != 160) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 128 or 160");
-  p.nbm = (d->M + BM - 1) / BM;
+  // tile height / ring depth: 0 = 128 rows, 2 stages; 1 = 128 rows, 3 stages; 2 = 256 rows, 3 stages
+  int variant = 0;
+  if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
+  const int bm = variant == 2 ? 256 : 128;
+  p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
   hipStream_t s = (hipStream_t)stream;
-  return tile == 160 ? dispatch<5>(p, d->amode, d->epi, s) : dispatch<4>(p, d->amode, d->epi, s);
+  if (tile == 160) {
+    if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
+    if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);
+    return dispatch<2, 5, 2>(p, d->amode, d->epi, s);
+  }
+  if (variant == 2) return dispatch<4, 4, 3>(p, d->amode, d->epi, s);
+  if (variant == 1) return dispatch<2, 4, 3>(p, d->amode, d->epi, s);
+  return dispatch<2, 4, 2>(p, d->amode, d->epi, s);
 }

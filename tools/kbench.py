@@ -102,7 +102,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "one"):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -113,3 +113,19 @@ if __name__ == "__main__":
         bench_attn(lat=lat)
     if which in ("norm", "all"):
         bench_norm(lat=lat)
+
+
+def bench_one():
+    """kbench.py one <kind> M N K : a single GEMM shape, few iterations (for rocprofv3 --pmc)."""
+    kind, M, N, K = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    A, W = rb(M, K), rb(N, K)
+    bias = torch.randn(N, device=dev)
+    geglu = kind == "geglu"
+    R1 = rb(M, N) if kind == "res" else None
+    out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: ops.gemm(A, W, M=M, N=N, K=K, bias=bias, R1=R1, geglu=geglu, out=out), iters=3, warm=1)
+    print(f"{kind} M={M} N={N} K={K}: {ms:.3f} ms {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "one":
+    bench_one()
