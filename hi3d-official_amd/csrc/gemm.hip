@@ -64,6 +64,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   const int tn = lid % p.nbn, tm = lid / p.nbn;
   const int m0 = tm * BM, n0 = tn * BN;
 
+
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
   // (r&7 within an 8-row, 1 KiB DMA piece); lane slot s carries source chunk
   // s ^ swz(r).
@@ -380,8 +381,10 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile = t; }
   }
   if (tile != 128 && tile != 160) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 128 or 160");
-  // tile height / ring depth: 0 = 128 rows, 2 stages; 1 = 128 rows, 3 stages; 2 = 256 rows, 3 stages
-  int variant = 0;
+  // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU; 1 = 128 rows, 3 stages;
+  // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU.  Measured on MI355X:
+  // 2 wins by 2-8 % once there are enough 256-row tiles to fill the chip several times.
+  int variant = ((long)((d->M + 255) / 256) * ((d->N + tile - 1) / tile) >= 1024) ? 2 : 0;
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
   const int bm = variant == 2 ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
@@ -395,4 +398,16 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (variant == 2) return dispatch<4, 4, 3>(p, d->amode, d->epi, s);
   if (variant == 1) return dispatch<2, 4, 3>(p, d->amode, d->epi, s);
   return dispatch<2, 4, 2>(p, d->amode, d->epi, s);
+}
+
+// debug aid: resident blocks per CU the runtime predicts for a kernel variant
+extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
+  int n = -1;
+#define OCC(WM, NT, NS) if (wm == WM && nt == NT && ns == NS) { \
+    constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2); \
+    hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, WM * 128, smem); }
+  OCC(2, 5, 2) OCC(2, 4, 2) OCC(4, 5, 3) OCC(4, 4, 3) OCC(2, 5, 3) OCC(2, 4, 3)
+#undef OCC
+  return n;
 }
