@@ -81,18 +81,28 @@ __global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__
   if (tid < 64) partial[((long)inst * nblk + blk) * 64 + tid] = gs[tid];
 }
 
-// one block of 64 threads per instance: thread = (group, {sum|sumsq})
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                   int nblk, double inv_count, float eps) {
-  const int inst = blockIdx.x, tid = threadIdx.x;
+// one block per instance: thread = (part, group, {sum|sumsq}); 16 parts walk the partials
+// in a fixed interleave, then a fixed-order fp64 combine (bitwise reproducible)
+constexpr int GN_FIN_PARTS = 16;
+__global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                                        float* __restrict__ stats, int nblk,
+                                                                        double inv_count, float eps) {
+  const int inst = blockIdx.x, tid = threadIdx.x & 63, part = threadIdx.x >> 6;
+  __shared__ double sh[GN_FIN_PARTS][64];
   double acc = 0.0;
-  for (int b = 0; b < nblk; ++b) acc += (double)partial[((long)inst * nblk + b) * 64 + tid];
-  __shared__ double sh[64];
-  sh[tid] = acc;
+  for (int b = part; b < nblk; b += GN_FIN_PARTS) acc += (double)partial[((long)inst * nblk + b) * 64 + tid];
+  sh[part][tid] = acc;
   __syncthreads();
-  if ((tid & 1) == 0) {
-    const double mean = sh[tid] * inv_count;
-    double var = sh[tid + 1] * inv_count - mean * mean;
+  if (part == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < GN_FIN_PARTS; ++q) tot += sh[q][tid];
+    sh[0][tid] = tot;
+  }
+  __syncthreads();
+  if (part == 0 && (tid & 1) == 0) {
+    const double mean = sh[0][tid] * inv_count;
+    double var = sh[0][tid + 1] * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
     stats[inst * 64 + tid] = (float)mean;
     stats[inst * 64 + tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -238,7 +248,7 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, partial, P, C, nblk);
   HI3D_LAUNCH_CHECK();
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64), 0, s, partial, stats, nblk, inv_count, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, partial, stats, nblk, inv_count, eps);
   HI3D_LAUNCH_CHECK();
   const int ablk = (P + GN_APPLY_PPB - 1) / GN_APPLY_PPB;
   if (apply_silu)
