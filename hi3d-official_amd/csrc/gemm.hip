@@ -38,6 +38,7 @@ constexpr int BK = 64;
 //        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
 template <int WM, int NT, int NS, int AMODE, int EPI>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p) {
+#if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
   constexpr int BM = WM * 64, BN = 32 * NT;
   constexpr int A_BYTES = BM * BK * 2;
@@ -66,89 +67,99 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 
 
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
-  // (r&7 within an 8-row, 1 KiB DMA piece); lane slot s carries source chunk
-  // s ^ swz(r).
+  // (r&7 within an 8-row, 1 KiB DMA piece); lane slot s carries source chunk s ^ swz(r).
+  // All global addressing is 32-bit: a buffer descriptor based at this block's first
+  // row (or frame), a per-lane byte offset fixed for the whole K loop, and a scalar
+  // offset that walks K (and the conv taps).  Out-of-range lanes (M/N tails, conv
+  // padding) carry an offset beyond num_records: the buffer unit returns zeros for them.
+  constexpr unsigned INV = 0x80000000u;
   const int lrow = lane >> 3, lslot = lane & 7;
-  int a_row_valid = 0;          // bit i: row i of this thread is < M
-  long a_base[4];               // dense: byte offset of row; conv: see below
-  int a_p0[4], a_p1[4];         // conv3x3: oy, ox ; convt3: t
-  int a_chunk[4];
+  unsigned a_voff[4];           // byte offset of this lane's 16-byte chunk (or INV)
+  int a_mask[4];                // conv: bit `tap` set when the tap is inside the image / clip
+  int a_p0[4], a_p1[4];         // up2x only: output pixel coordinates
+  const char* a_origin;
+  if (AMODE == HI3D_A_DENSE) {
+    a_origin = p.A + (long)m0 * p.lda * 2;
+  } else if (AMODE == HI3D_A_CONV3X3) {
+    const int f0 = m0 / (p.Hout * p.Wout);
+    // origin shifted back by one row + one pixel so that every tap offset is >= 0
+    a_origin = p.A + ((long)f0 * p.Hin * p.Win - (p.up2x ? 0 : (p.Win + 1))) * p.Cin * 2;
+  } else {
+    a_origin = p.A + ((long)m0 - p.HW) * p.Cin * 2;      // one frame back: temporal tap 0
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (w * 4 + i) * 8 + lrow;
     const int m = m0 + r;
-    a_chunk[i] = lslot ^ ((r >> 1) & 7);
+    const int chunk = lslot ^ ((r >> 1) & 7);
     const bool ok = m < p.M;
-    a_row_valid |= ok ? (1 << i) : 0;
-    const int mm = ok ? m : 0;
+    a_mask[i] = 0; a_p0[i] = a_p1[i] = 0;
     if (AMODE == HI3D_A_DENSE) {
-      a_base[i] = (long)mm * p.lda * 2;
-      a_p0[i] = a_p1[i] = 0;
+      a_voff[i] = ok ? (unsigned)(r * p.lda * 2 + chunk * 16) : INV;
     } else if (AMODE == HI3D_A_CONV3X3) {
       const int hw = p.Hout * p.Wout;
+      const int mm = ok ? m : m0;
       const int f = mm / hw, rem = mm - f * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_base[i] = (long)f * p.Hin * p.Win;       // pixel index of frame origin
-      a_p0[i] = oy * p.stride; a_p1[i] = ox * p.stride;
+      const int frel = f - m0 / hw;
+      if (p.up2x) {
+        a_p0[i] = oy; a_p1[i] = ox;
+        a_voff[i] = ok ? (unsigned)((frel * p.Hin * p.Win) * p.Cin * 2 + chunk * 16) : INV;
+      } else {
+        const int iy = oy * p.stride, ix = ox * p.stride;
+        a_voff[i] = ok ? (unsigned)((((frel * p.Hin + iy) * p.Win + ix) * p.Cin) * 2 + chunk * 16) : INV;
+        const int ym = (iy >= 1 ? 1 : 0) | 2 | (iy + 1 < p.Hin ? 4 : 0);
+        const int xm = (ix >= 1 ? 1 : 0) | 2 | (ix + 1 < p.Win ? 4 : 0);
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mk |= (((ym >> (t / 3)) & (xm >> (t % 3))) & 1) << t;
+        a_mask[i] = mk;
+      }
     } else {
-      const int f = mm / p.HW;                    // frame index (b*T + t)
-      a_base[i] = (long)mm * p.Cin * 2;
-      a_p0[i] = f % p.T; a_p1[i] = 0;
+      const int t = ((ok ? m : m0) / p.HW) % p.T;
+      a_voff[i] = ok ? (unsigned)(r * p.Cin * 2 + chunk * 16) : INV;
+      a_mask[i] = (t >= 1 ? 1 : 0) | 2 | (t + 1 < p.T ? 4 : 0);
     }
   }
-  long b_base[W_PIECES]; int b_chunk[W_PIECES]; int b_row_valid = 0;
+  unsigned b_voff[W_PIECES];
 #pragma unroll
   for (int i = 0; i < W_PIECES; ++i) {
     const int q = w + NW * i;                      // W piece (8 rows) handled by this wave
     const int j = q * 8 + lrow;                    // row of the W tile, 0..BN-1
     const int jw = j % (16 * NT);                  // row within its wave tile
     const int fi = (jw / (4 * NT)) * 4 + (jw & 3); // MFMA row index that reads it
-    b_chunk[i] = lslot ^ ((fi >> 1) & 7);
-    const int n = n0 + j;
-    const bool ok = n < p.N && q < 4 * NT;
-    b_row_valid |= ok ? (1 << i) : 0;
-    b_base[i] = (long)(ok ? n : 0) * p.ldw * 2;
+    const int chunk = lslot ^ ((fi >> 1) & 7);
+    b_voff[i] = (n0 + j < p.N) ? (unsigned)(j * p.ldw * 2 + chunk * 16) : INV;
   }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_origin, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)n0 * p.ldw * 2), 0, 0x7fffffff, 0x00020000);
 
-  const char* zero = (const char*)hi3d_zero_page;
   int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
 
   auto issue = [&](int kt, int st) {
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
-    const int k0 = kt * BK;
-    int dy = 0, dx = 0;
-    if (AMODE == HI3D_A_CONV3X3) { dy = tap / 3; dx = tap - dy * 3; }
+    unsigned soff;                                 // scalar byte offset of this K chunk
+    if (AMODE == HI3D_A_DENSE) soff = kt * (BK * 2);
+    else if (AMODE == HI3D_A_CONV3X3) soff = p.up2x ? c0 * 2 : (((tap / 3) * p.Win + (tap % 3)) * p.Cin + c0) * 2;
+    else soff = (tap * p.HW * p.Cin + c0) * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const char* src;
-      bool ok = (a_row_valid >> i) & 1;
-      if (AMODE == HI3D_A_DENSE) {
-        src = p.A + a_base[i] + (long)(k0 + a_chunk[i] * 8) * 2;
-      } else if (AMODE == HI3D_A_CONV3X3) {
-        int iy = a_p0[i] + dy - 1, ix = a_p1[i] + dx - 1;
-        if (p.up2x) {
-          ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
-          iy >>= 1; ix >>= 1;
-        } else {
-          ok = ok && iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
-        }
-        src = p.A + ((a_base[i] + (long)iy * p.Win + ix) * p.Cin + c0 + a_chunk[i] * 8) * 2;
-      } else {
-        const int tt = a_p0[i] + tap - 1;
-        ok = ok && tt >= 0 && tt < p.T;
-        src = p.A + a_base[i] + ((long)(tap - 1) * p.HW * p.Cin + c0 + a_chunk[i] * 8) * 2;
+      unsigned vo = a_voff[i];
+      if (AMODE == HI3D_A_CONV3X3 && p.up2x) {
+        const int iy = a_p0[i] + tap / 3 - 1, ix = a_p1[i] + tap % 3 - 1;   // on the virtual 2H x 2W grid
+        const bool in = iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
+        vo = (in && vo != INV) ? vo + (unsigned)(((iy >> 1) * p.Win + (ix >> 1)) * p.Cin * 2) : INV;
+      } else if (AMODE != HI3D_A_DENSE) {
+        vo = ((a_mask[i] >> tap) & 1) ? vo : INV;
       }
-      if (p.dbg & 1) ok = false;   // timing experiment only (HI3D_GEMM_DEBUG)
-      lds_dma16(ok ? src : zero, sA + (w * 4 + i) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(sA + (w * 4 + i) * 1024), 16, vo, soff, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
       const int q = w + NW * i;
-      if (q < 4 * NT) {                           // wave-uniform
-        const char* src = p.W + b_base[i] + (long)(k0 + b_chunk[i] * 8) * 2;
-        lds_dma16((((b_row_valid >> i) & 1) && !(p.dbg & 2)) ? src : zero, sB + q * 1024);
-      }
+      if (q < 4 * NT)                               // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (LDS_AS void*)(sB + q * 1024), 16, b_voff[i], kt * (BK * 2), 0, 0);
     }
     if (AMODE != HI3D_A_DENSE) { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
   };
@@ -233,11 +244,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
         const int cl = wn * 16 * NT + fg * 4 * NT + nt * 4;    // tile-local column of acc[mt][nt][0]
         const int n = n0 + cl;
         f32x4 v = acc[mt][nt];
-        if (p.bias && n < p.N) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
-          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-        }
         if (EPI == HI3D_EPI_GEGLU) {
+          if (p.bias && n < p.N) {
+            const f32x4 b = *(const f32x4*)(p.bias + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+          }
           float2 o; o.x = v[0] * gelu_erf_f(v[2]); o.y = v[1] * gelu_erf_f(v[3]);
           *(float2*)(trow + (cl >> 1) * 4) = o;
         } else {
@@ -256,7 +267,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       const bool full = (n + 8 <= N_out) && p.vec8;          // else: only the first 4 columns exist / are aligned
       if (EPI == HI3D_EPI_AFFINE) {
-        const int grp = m / p.rpg;
+        const int grp = (p.rowvec || p.a1 || p.a2) ? m / p.rpg : 0;
+        if (p.bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + n);
+          v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+          if (n + 8 <= N_out) { const f32x4 b1 = *(const f32x4*)(p.bias + n + 4); v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3]; }
+        }
         if (p.rowvec) {
           const float* rv = p.rowvec + (long)grp * p.ldrv + n;
           const f32x4 r0 = *(const f32x4*)rv;
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
     }
     if (half == 0) __syncthreads();
   }
+#endif
 }
 
 template <int WM, int NT, int NS, int AMODE, int EPI>
