@@ -169,9 +169,16 @@ def main():
         dom_is_gemm = g_ms >= at["ms"]
         k_ms, k_fl, k_n = (g_ms, g_fl, g_n) if dom_is_gemm else (at["ms"], at["flops"], at["launches"])
         ach = k_fl / (k_ms * 1e-3) / 1e12
+        # HBM traffic per launch of that kernel from rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py);
+        # measured offline because counters serialise kernels -- null if no profile is committed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{a.config}.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel")
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                            "launches_per_step": k_n // a.steps, "avg_launch_ms": round(k_ms / k_n, 4),
                            "share_of_step": round(k_ms / a.steps / ms_per_step, 3)}
         out["kernels_ms_per_step"] = {f: round(d["ms"] / a.steps, 3) for f, d in fams}

@@ -398,10 +398,10 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile = t; }
   }
   if (tile != 128 && tile != 160) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 128 or 160");
-  // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU; 1 = 128 rows, 3 stages;
-  // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU.  Measured on MI355X:
-  // 2 wins by 2-8 % once there are enough 256-row tiles to fill the chip several times.
-  int variant = ((long)((d->M + 255) / 256) * ((d->N + tile - 1) / tile) >= 1024) ? 2 : 0;
+  // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU (default: fastest at every
+  // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
+  // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU.
+  int variant = 0;
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
   const int bm = variant == 2 ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
