@@ -175,7 +175,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{a.config}.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel")
+            traffic = json.load(open(tpath)).get("gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel", {}).get("bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

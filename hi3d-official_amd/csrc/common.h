@@ -48,6 +48,23 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// two GELUs at once on packed fp32 (v_pk_mul/fma_f32): halves the VALU work of the GEGLU epilogue
+__device__ __forceinline__ hi3d_f2 gelu_erf_f2(hi3d_f2 x) {
+  hi3d_f2 z = {fabsf(x[0]), fabsf(x[1])};
+  z = z * 0.70710678118654752f;
+  const hi3d_f2 d = z * 0.3275911f + 1.0f;
+  const hi3d_f2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  hi3d_f2 poly = t * 1.061405429f - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const hi3d_f2 a = z * z * -1.4426950408889634f;
+  const hi3d_f2 ex = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const hi3d_f2 e = 1.0f - poly * t * ex;
+  const hi3d_f2 se = {copysignf(e[0], x[0]), copysignf(e[1], x[1])};
+  return x * 0.5f * (se + 1.0f);
+}
+
 // 16-byte LDS-DMA: each lane supplies its own global source, the LDS destination
 // is the wave-uniform `lds_wave_base` + lane*16 (hardware adds the lane part).
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {

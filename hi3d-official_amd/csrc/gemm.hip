@@ -249,7 +249,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
             const f32x4 b = *(const f32x4*)(p.bias + n);
             v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
           }
-          float2 o; o.x = v[0] * gelu_erf_f(v[2]); o.y = v[1] * gelu_erf_f(v[3]);
+          const hi3d_f2 gl = gelu_erf_f2(hi3d_f2{v[2], v[3]});
+          float2 o; o.x = v[0] * gl[0]; o.y = v[1] * gl[1];
           *(float2*)(trow + (cl >> 1) * 4) = o;
         } else {
           *(f32x4*)(trow + cl * 4) = v;
