@@ -25,7 +25,7 @@ struct GemmParams {
   const unsigned short* R1; const unsigned short* R2; const float* a1; const float* a2;
   void* out;
   int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8;
-  int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW;
+  int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW, pad;
   int nbm, nbn;
 };
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   } else if (AMODE == HI3D_A_CONV3X3) {
     const int f0 = m0 / (p.Hout * p.Wout);
     // origin shifted back by one row + one pixel so that every tap offset is >= 0
-    a_origin = p.A + ((long)f0 * p.Hin * p.Win - (p.up2x ? 0 : (p.Win + 1))) * p.Cin * 2;
+    a_origin = p.A + ((long)f0 * p.Hin * p.Win - (p.up2x ? 0 : (p.Win + 1) * p.pad)) * p.Cin * 2;
   } else {
     a_origin = p.A + ((long)m0 - p.HW) * p.Cin * 2;      // one frame back: temporal tap 0
   }
@@ -108,8 +108,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
       } else {
         const int iy = oy * p.stride, ix = ox * p.stride;
         a_voff[i] = ok ? (unsigned)((((frel * p.Hin + iy) * p.Win + ix) * p.Cin) * 2 + chunk * 16) : INV;
-        const int ym = (iy >= 1 ? 1 : 0) | 2 | (iy + 1 < p.Hin ? 4 : 0);
-        const int xm = (ix >= 1 ? 1 : 0) | 2 | (ix + 1 < p.Win ? 4 : 0);
+        int ym = 0, xm = 0;                          // bit d: tap row/column d lies inside the image
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          ym |= (iy + d - p.pad >= 0 && iy + d - p.pad < p.Hin) ? (1 << d) : 0;
+          xm |= (ix + d - p.pad >= 0 && ix + d - p.pad < p.Win) ? (1 << d) : 0;
+        }
         int mk = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) mk |= (((ym >> (t / 3)) & (xm >> (t % 3))) & 1) << t;
@@ -363,7 +367,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.out = d->out; p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldo = d->ldo;
   p.ldr1 = d->ldr1; p.ldr2 = d->ldr2; p.ldrv = d->ldrv > 0 ? d->ldrv : d->N; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.rpg = d->rows_per_group; p.out_fp32 = d->out_fp32;
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
-  p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW;
+  p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW; p.pad = d->pad_br_only ? 0 : 1;
   if (d->amode == HI3D_A_DENSE) {
     if (d->lda < d->K || (d->lda % 8)) HI3D_FAIL(HI3D_EALIGN, "gemm: lda < K or lda % 8 != 0");
   } else if (d->amode == HI3D_A_CONV3X3) {
@@ -371,8 +375,10 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (d->Hin <= 0 || d->Win <= 0 || d->Hout <= 0 || d->Wout <= 0) HI3D_FAIL(HI3D_EINVAL, "conv3x3: bad geometry");
     if (d->stride != 1 && d->stride != 2) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: stride must be 1 or 2");
     if (d->up2x && d->stride != 1) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: up2x needs stride 1");
-    const int eh = d->up2x ? 2 * d->Hin : (d->Hin + 2 - 3) / d->stride + 1;
-    const int ew = d->up2x ? 2 * d->Win : (d->Win + 2 - 3) / d->stride + 1;
+    if (d->pad_br_only && d->up2x) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: pad_br_only cannot be combined with up2x");
+    const int padt = d->pad_br_only ? 1 : 2;     // total padding per axis
+    const int eh = d->up2x ? 2 * d->Hin : (d->Hin + padt - 3) / d->stride + 1;
+    const int ew = d->up2x ? 2 * d->Win : (d->Win + padt - 3) / d->stride + 1;
     if (eh != d->Hout || ew != d->Wout) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: Hout/Wout inconsistent with Hin/Win/stride");
     if (d->M % (d->Hout * d->Wout)) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: M not a multiple of Hout*Wout");
   } else if (d->amode == HI3D_A_CONVT3) {

@@ -147,6 +147,36 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+__global__ void vae_posterior_kernel(const float* __restrict__ mom, const float* __restrict__ wq,
+                                     const float* __restrict__ bq, const float* __restrict__ noise,
+                                     float* __restrict__ z, int Cz, int HW, int ldm, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;    // over N*HW pixels
+  if (idx >= total) return;
+  const int p = (int)(idx % HW); const long n = idx / HW;
+  const int C2 = 2 * Cz;
+  float mi[16], mo[16];
+  for (int c = 0; c < C2; ++c) mi[c] = mom[idx * ldm + c];
+  for (int co = 0; co < C2; ++co) {
+    float acc = bq[co];
+    for (int ci = 0; ci < C2; ++ci) acc += wq[co * C2 + ci] * mi[ci];
+    mo[co] = acc;
+  }
+  for (int c = 0; c < Cz; ++c) {
+    float v = mo[c];
+    if (noise) {
+      const float lv = fminf(fmaxf(mo[Cz + c], -30.0f), 20.0f);
+      v += expf(0.5f * lv) * noise[(n * Cz + c) * HW + p];
+    }
+    z[(n * Cz + c) * HW + p] = v;
+  }
+}
+
+__global__ void v02_blend_kernel(float* __restrict__ lat, const float* __restrict__ noise,
+                                 const float* __restrict__ z, long n, float alpha, float sigma) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    lat[i] = lat[i] * (1.0f - alpha) + (noise[i] * sigma + z[i]) * alpha;
+}
+
 inline unsigned grid_for(long n, int block, long cap = 65536) {
   long g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -256,6 +286,26 @@ extern "C" int hi3d_softmax_rows(const float* s, void* p, int32_t R, int32_t N, 
   if (N > 16384 || ldp > 16384) HI3D_FAIL(HI3D_ESHAPE, "softmax_rows: rows longer than 16384 not supported");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, s, (unsigned short*)p, N, lds_, ldp,
                      scale * 1.4426950408889634f);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_vae_posterior(const float* mom, const float* wq, const float* bq, const float* noise,
+                                  float* z, int32_t N, int32_t Cz, int32_t HW, int32_t ldm, void* stream) {
+  if (!mom || !wq || !bq || !z) HI3D_FAIL(HI3D_EINVAL, "vae_posterior: null pointer");
+  if (N <= 0 || HW <= 0 || Cz <= 0 || Cz > 8 || ldm < 2 * Cz) HI3D_FAIL(HI3D_EINVAL, "vae_posterior: bad size");
+  const long total = (long)N * HW;
+  hipLaunchKernelGGL(vae_posterior_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     mom, wq, bq, noise, z, Cz, HW, ldm, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_v02_blend(float* lat, const float* noise, const float* z, int64_t n, float alpha,
+                              float sigma, void* stream) {
+  if (!lat || !noise || !z) HI3D_FAIL(HI3D_EINVAL, "v02_blend: null pointer");
+  if (n <= 0) HI3D_FAIL(HI3D_EINVAL, "v02_blend: non-positive size");
+  hipLaunchKernelGGL(v02_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, lat, noise, z, (long)n, alpha, sigma);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

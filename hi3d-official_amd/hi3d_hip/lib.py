@@ -19,7 +19,7 @@ EXPORTS = [
     "hi3d_gn_workspace_floats", "hi3d_groupnorm_silu", "hi3d_layernorm",
     "hi3d_concat_channels", "hi3d_timestep_embedding", "hi3d_silu_f32_to_bf16",
     "hi3d_cfg_prepare", "hi3d_sampler_step", "hi3d_nchw_f32_to_nhwc_bf16",
-    "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows",
+    "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows", "hi3d_vae_posterior", "hi3d_v02_blend",
 ]
 
 A_DENSE, A_CONV3X3, A_CONVT3 = 0, 1, 2
@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("amode", C.c_int32), ("epi", C.c_int32), ("out_fp32", C.c_int32),
         ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
         ("Wout", C.c_int32), ("stride", C.c_int32), ("up2x", C.c_int32),
-        ("T", C.c_int32), ("HW", C.c_int32), ("tile_n", C.c_int32),
+        ("T", C.c_int32), ("HW", C.c_int32), ("tile_n", C.c_int32), ("pad_br_only", C.c_int32),
     ]
 
 
@@ -79,6 +79,8 @@ def load():
         "hi3d_nhwc_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "hi3d_vae_latent_prepare": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "hi3d_softmax_rows": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp]),
+        "hi3d_vae_posterior": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "hi3d_v02_blend": (C.c_int, [vp, vp, vp, i64, f32, f32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -83,6 +83,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         d.amode = _l.A_CONV3X3
         for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "up2x"):
             setattr(d, k, int(conv3x3[k]))
+        d.pad_br_only = int(conv3x3.get("pad_br_only", 0))
     elif convt3 is not None:
         d.amode = _l.A_CONVT3
         d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])
@@ -264,3 +265,19 @@ def softmax_rows(s, R, N, ldp, scale):
     if prof:
         prof.end("softmax_rows", 0.0, 4.0 * R * N + 2.0 * R * ldp, t0)
     return p
+
+
+def vae_posterior(mom, wq, bq, noise, N, Cz, H, W):
+    """mom fp32 [N*H*W, ldm] -> z fp32 [N, Cz, H, W] (sample if noise is given, else the mode)."""
+    z = torch.empty((N, Cz, H, W), device=mom.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_vae_posterior(_p(mom), _p(wq), _p(bq), _p(noise), _p(z), N, Cz, H * W, mom.stride(0), _stream()),
+             "hi3d_vae_posterior")
+    return z
+
+
+def v02_blend(lat, noise, z, alpha, sigma):
+    for t in (lat, noise, z):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _l.Hi3dError("v02_blend: fp32 contiguous tensors required")
+    _l.check(_lib.hi3d_v02_blend(_p(lat), _p(noise), _p(z), lat.numel(), float(alpha), float(sigma), _stream()), "hi3d_v02_blend")
+    return lat

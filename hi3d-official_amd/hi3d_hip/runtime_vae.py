@@ -126,3 +126,88 @@ class VAEDecoderRuntime:
         ocp = W["conv_out.b"].numel()
         out = self._conv(h, "conv_out", N, H, Wd, cin, ocp, out_fp32=True)
         return ops.tokens_to_nchw(out, N, self.out_ch, H, Wd, ocp)
+
+
+class _ResnetMixin:
+    """conv / ResnetBlock / attention helpers shared by the encoder (same arithmetic as the
+    decoder's; reference model.py:131-151,161-200)."""
+    _conv = VAEDecoderRuntime._conv
+    _resnet = VAEDecoderRuntime._resnet
+    _attn = VAEDecoderRuntime._attn
+
+
+class VAEEncoderRuntime(_ResnetMixin):
+    """AutoencoderKL ENCODER (stage-2 pre-loop, once per clip):
+    Encoder.forward (sgm/modules/diffusionmodules/model.py:576-601) + quant_conv +
+    DiagonalGaussianRegularizer (models/autoencoder.py:468-488, regularizers/__init__.py:21-31).
+    The stride-2 Downsample pads bottom/right only (model.py:76-90): `pad_br_only` conv."""
+
+    def __init__(self, state_dict, ddconfig, device, prefix=""):
+        self.dd, self.dev = dict(ddconfig), torch.device(device)
+        dd = self.dd
+        self.ch, self.mult, self.nres = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+        if self.ch % 64:
+            raise ops._l.Hi3dError("VAE encoder runtime needs ch % 64 == 0 (Hi3D uses ch=128)")
+        if not dd.get("double_z", True):
+            raise ops._l.Hi3dError("double_z=False not supported")
+        sd, P, dev = state_dict, prefix, self.dev
+        g = lambda k: sd[P + k].detach().to(dev)
+        f32 = lambda k: pack.f32(g(k))
+        W = {}
+        E = "encoder."
+        W["conv_in.w"] = pack.pack_conv3x3(g(E + "conv_in.weight"), cin_pad=CZ_PAD); W["conv_in.b"] = f32(E + "conv_in.bias")
+
+        def resnet(p):
+            for n in ("norm1", "norm2"):
+                W[f"{p}.{n}.g"] = f32(f"{E}{p}.{n}.weight"); W[f"{p}.{n}.b"] = f32(f"{E}{p}.{n}.bias")
+            for n in ("conv1", "conv2"):
+                W[f"{p}.{n}.w"] = pack.pack_conv3x3(g(f"{E}{p}.{n}.weight")); W[f"{p}.{n}.b"] = f32(f"{E}{p}.{n}.bias")
+            if (P + E + p + ".nin_shortcut.weight") in sd:
+                W[p + ".nin.w"] = pack.pack_conv1x1(g(f"{E}{p}.nin_shortcut.weight")); W[p + ".nin.b"] = f32(f"{E}{p}.nin_shortcut.bias")
+
+        for lvl in range(len(self.mult)):
+            for b in range(self.nres):
+                resnet(f"down.{lvl}.block.{b}")
+            if lvl != len(self.mult) - 1:
+                W[f"down.{lvl}.ds.w"] = pack.pack_conv3x3(g(f"{E}down.{lvl}.downsample.conv.weight"))
+                W[f"down.{lvl}.ds.b"] = f32(f"{E}down.{lvl}.downsample.conv.bias")
+        resnet("mid.block_1"); resnet("mid.block_2")
+        a = "mid.attn_1"
+        W[a + ".norm.g"] = f32(E + a + ".norm.weight"); W[a + ".norm.b"] = f32(E + a + ".norm.bias")
+        W[a + ".qkv.w"] = pack._bf16(torch.cat([pack.pack_conv1x1(g(f"{E}{a}.{n}.weight")) for n in ("q", "k", "v")], 0))
+        W[a + ".qkv.b"] = torch.cat([f32(f"{E}{a}.{n}.bias") for n in ("q", "k", "v")]).contiguous()
+        W[a + ".o.w"] = pack.pack_conv1x1(g(E + a + ".proj_out.weight")); W[a + ".o.b"] = f32(E + a + ".proj_out.bias")
+        W["norm_out.g"] = f32(E + "norm_out.weight"); W["norm_out.b"] = f32(E + "norm_out.bias")
+        self.zc = dd["z_channels"]
+        W["conv_out.w"] = pack.pack_conv3x3(g(E + "conv_out.weight")); W["conv_out.b"] = f32(E + "conv_out.bias")
+        W["q.w"] = f32("quant_conv.weight").reshape(2 * self.zc, -1).contiguous(); W["q.b"] = f32("quant_conv.bias")
+        self.W = W
+
+    @torch.no_grad()
+    def encode(self, x, noise=None):
+        """x: [N, 3, H, W] in [-1, 1] -> z fp32 [N, Cz, H/8, W/8]; `noise` (same shape as z)
+        selects posterior.sample(), None the mode."""
+        W = self.W
+        N, _, H, Wd = x.shape
+        h = ops.nchw_to_tokens(x.to(self.dev), CZ_PAD)
+        cin = self.ch
+        h = self._conv(h, "conv_in", N, H, Wd, CZ_PAD, cin)
+        for lvl in range(len(self.mult)):
+            cout = self.ch * self.mult[lvl]
+            for b in range(self.nres):
+                h = self._resnet(f"down.{lvl}.block.{b}", h, N, H, Wd, cin, cout)
+                cin = cout
+            if lvl != len(self.mult) - 1:
+                if H % 2 or Wd % 2:
+                    raise ops._l.Hi3dError("encoder input height/width must be divisible by 8")
+                h = ops.gemm(h, W[f"down.{lvl}.ds.w"], M=N * (H // 2) * (Wd // 2), N=cin, K=9 * cin, bias=W[f"down.{lvl}.ds.b"],
+                             conv3x3=dict(Hin=H, Win=Wd, Cin=cin, Hout=H // 2, Wout=Wd // 2, stride=2, up2x=0, pad_br_only=1))
+                H, Wd = H // 2, Wd // 2
+        h = self._resnet("mid.block_1", h, N, H, Wd, cin, cin)
+        h = self._attn("mid.attn_1", h, N, H * Wd, cin)
+        h = self._resnet("mid.block_2", h, N, H, Wd, cin, cin)
+        h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6)
+        mom = self._conv(h, "conv_out", N, H, Wd, cin, 2 * self.zc, out_fp32=True)
+        if noise is not None:
+            noise = noise.to(self.dev, torch.float32).contiguous()
+        return ops.vae_posterior(mom, W["q.w"], W["q.b"], noise, N, self.zc, H, Wd)

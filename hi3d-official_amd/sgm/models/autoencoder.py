@@ -2,7 +2,7 @@
 
 Holds the reference's parameter names (`encoder.*`, `decoder.*`, `quant_conv`,
 `post_quant_conv`); `decode` runs hi3d_hip.runtime_vae.VAEDecoderRuntime (gfx950 kernels).
-`encode` (stage-2 pre-loop only) is not built yet and says so."""
+`encode` runs VAEEncoderRuntime (stage-2 pre-loop: once per frame, once per clip)."""
 import torch
 
 from ..util import ParamTree
@@ -95,13 +95,33 @@ class AutoencoderKL(ParamTree):
             raise RuntimeError("AutoencoderKL.decode runs on the MI355X only (no CPU path in this framework)")
         return self.runtime(z.device).decode(z).to(z.dtype)
 
-    def encode(self, x, **kwargs):
-        raise NotImplementedError("VAE encoder (stage-2 pre-loop, once per clip) is not built yet: "
-                                  "SURVEY.md section 8f rank 2")
+    sample_posterior = True      # DiagonalGaussianRegularizer(sample=True), models/autoencoder.py:508-520
+
+    def encoder_runtime(self, device):
+        from hi3d_hip.runtime_vae import VAEEncoderRuntime
+        p0 = next(self.parameters())
+        key = (torch.device(device), p0.data_ptr(), p0._version, p0.dtype)
+        if getattr(self, "_enc_runtime", None) is None or self._enc_key != key:
+            self._enc_runtime = VAEEncoderRuntime(self.state_dict(), self.ddconfig, device)
+            self._enc_key = key
+        return self._enc_runtime
+
+    @torch.no_grad()
+    def encode(self, x, return_reg_log=False, noise=None, **kwargs):
+        """x: [N, 3, H, W] -> z [N, 4, H/8, W/8].  Like the reference, the posterior is SAMPLED
+        with noise drawn on the CPU generator (distributions.py:37-41) unless `noise` is given;
+        AutoencoderKLModeOnly returns the mode."""
+        if not x.is_cuda:
+            raise RuntimeError("AutoencoderKL.encode runs on the MI355X only (no CPU path in this framework)")
+        n, _, h, w = x.shape
+        if self.sample_posterior and noise is None:
+            noise = torch.randn((n, self.ddconfig["z_channels"], h // 8, w // 8))
+        z = self.encoder_runtime(x.device).encode(x, noise if self.sample_posterior else None).to(x.dtype)
+        return (z, {}) if return_reg_log else z
 
     def forward(self, x, **kwargs):
         raise NotImplementedError("training forward is out of scope")
 
 
 class AutoencoderKLModeOnly(AutoencoderKL):
-    pass
+    sample_posterior = False

@@ -93,6 +93,11 @@ class DiffusionEngine(nn.Module):
         return torch.cat(outs, dim=0)
 
     @torch.no_grad()
+    def encode_first_stage_with_noise(self, x, noise=None):
+        """encode_first_stage with explicit posterior noise (tests / reproducible runs)."""
+        return self.scale_factor * self.first_stage_model.encode(x, noise=noise)
+
+    @torch.no_grad()
     def encode_first_stage(self, x):
         outs = [self.first_stage_model.encode(x[lo:hi]) for lo, hi in self._chunks(x.shape[0])]
         return self.scale_factor * torch.cat(outs, dim=0)

@@ -57,7 +57,8 @@ const char* hi3d_last_error(void);
  *                   openaimodel.py:284-290 emb_layers; 1x1 conv openaimodel.py:314)
  *   HI3D_A_CONV3X3 3x3 convolution, padding 1, on NHWC input [frames,Hin,Win,Cin];
  *                  m enumerates output pixels (frame, oy, ox); k = (ky*3+kx)*Cin+ci.
- *                  stride 1|2 (openaimodel.py:192-199 Downsample), optional
+ *                  stride 1|2 (openaimodel.py:192-199 Downsample; model.py:76-90 with
+ *                  pad_br_only), optional
  *                  nearest-2x upsample folded into the gather
  *                  (openaimodel.py:154-156 ; model.py:67-71).
  *                  (openaimodel.py:257-261,292-305 ResBlock convs; video_model.py:189,439)
@@ -98,6 +99,9 @@ typedef struct hi3d_gemm_desc {
   /* convt3:  (Cin shared) */
   int32_t T, HW;
   int32_t tile_n;       /* 0 = auto, else 128 or 160                          */
+  int32_t pad_br_only;  /* conv3x3: 1 = zero padding only at bottom/right (taps
+                           cover iy = oy*stride + 0..2): the VAE encoder's
+                           Downsample, model.py:76-90; 0 = padding 1 all round */
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
@@ -224,6 +228,19 @@ int hi3d_vae_latent_prepare(const float* z, const float* w, const float* b, void
  * N <= 16384.                                                                */
 int hi3d_softmax_rows(const float* s, void* p, int32_t R, int32_t N, int32_t lds,
                       int32_t ldp, float scale, void* stream);
+
+/* quant_conv (1x1, 2Cz -> 2Cz) + DiagonalGaussianDistribution (sgm/modules/distributions/
+ * distributions.py:24-41; regularizers/__init__.py:21-31) on the encoder's moments:
+ *   mom' = wq . mom + bq ; mean = mom'[0:Cz] ; logvar = clamp(mom'[Cz:2Cz], -30, 20)
+ *   z = mean + exp(0.5*logvar) * noise     (noise == NULL: the mode, z = mean)
+ * mom: fp32 channels-last [N*HW][ldm] (first 2Cz columns) ; noise, z: fp32 NCHW [N][Cz][HW]. */
+int hi3d_vae_posterior(const float* mom, const float* wq, const float* bq, const float* noise,
+                       float* z, int32_t N, int32_t Cz, int32_t HW, int32_t ldm, void* stream);
+
+/* Stage-2 (vid2vid refiner) re-noising blend, pipeline_i2v_eval_v02.py:127-132:
+ *   lat = lat*(1-alpha) + (noise*sigma + z)*alpha       elementwise, fp32, in place on lat */
+int hi3d_v02_blend(float* lat, const float* noise, const float* z, int64_t n, float alpha,
+                   float sigma, void* stream);
 
 #ifdef __cplusplus
 }

@@ -140,6 +140,73 @@ def gen_vae(name, ch, n, hw, wseed=1, iseed=0):
     print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
 
+def gen_vae_encode(name, ch, n, hw, wseed=1, iseed=0):
+    t0 = time.time()
+    AE = ref_import.ref("sgm.models.autoencoder.AutoencoderKL")
+    dd = vae_ddconfig(ch)
+    ae = AE(embed_dim=4, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}).eval()
+    synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
+    g = torch.Generator().manual_seed(iseed)
+    x = torch.rand((n, 3, hw, hw), generator=g) * 2 - 1
+    noise = torch.randn((n, 4, hw // 8, hw // 8), generator=g)
+    with torch.no_grad():
+        moments = ae.quant_conv(ae.encoder(x))
+        torch.manual_seed(1234)                       # posterior.sample() draws from the global CPU generator
+        z_sampled = ae.encode(x)
+        torch.manual_seed(1234)
+        ref_noise = torch.randn(z_sampled.shape)
+    sd = ae.state_dict()
+    fx = dict(kind="vae_encode", ddconfig=dd, weight_seed=wseed, key_prefix=VAE_PREFIX, x=x, moments=moments,
+              z_sampled=z_sampled, sample_noise=ref_noise, noise=noise,
+              shapes={k: tuple(v.shape) for k, v in sd.items()})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: moments {tuple(moments.shape)} absmax {moments.abs().max():.4f} ({time.time() - t0:.1f}s)")
+
+
+def gen_v02(name, cfg, T, hw, steps, max_scale, wseed=1, iseed=0):
+    """pipeline_i2v_eval_v02.py:103-135 with the reference sampler/denoiser/guider classes."""
+    import math
+    t0 = time.time()
+    unet = build_unet(cfg, wseed)
+    Wrapper = ref_import.ref("sgm.modules.diffusionmodules.wrappers.OpenAIWrapper")
+    Denoiser = ref_import.ref("sgm.modules.diffusionmodules.denoiser.Denoiser")
+    Sampler = ref_import.ref("sgm.modules.diffusionmodules.sampling.EulerEDMSampler")
+    append_dims = ref_import.ref("sgm.util.append_dims")
+    model = Wrapper(unet)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = Sampler(
+        num_steps=steps, verbose=False, device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                               "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": max_scale, "min_scale": 1.0}})
+    init, c, uc = synth.synth_conditioning(T, hw, hw, stage=2, seed=iseed, adm_in=cfg["adm_in_channels"])
+    g = torch.Generator().manual_seed(iseed + 100)
+    z_list = [torch.randn((1, 4, hw, hw), generator=g) * 0.8 for _ in range(T)]
+    extra = dict(image_only_indicator=torch.zeros(2, T), num_video_frames=T)
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+
+    with torch.no_grad():
+        sigmas = sampler.discretization(sampler.num_steps, device="cpu")
+        num_sigmas = len(sigmas)
+        s_in = init.new_ones([T])
+        latents = init.clone()
+        latents *= torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        z = z_list[0]
+        for i in sampler.get_sigma_gen(num_sigmas):
+            alpha = math.pow(0.5 * (1 + math.cos(i * 1.0 / sampler.num_steps)), 40.0)
+            for t in range(T):
+                latents[t:t + 1] = latents[t:t + 1] * (1 - alpha) + (init[t:t + 1] * append_dims(sigmas[i], z.ndim) + z_list[t]) * alpha
+            latents = sampler.step_call(denoiser, latents, i, s_in, sigmas, num_sigmas, c, uc)
+    fx = dict(kind="v02", cfg=cfg, T=T, steps=steps, max_scale=max_scale, weight_seed=wseed, key_prefix=UNET_PREFIX,
+              init=init, c=c, uc=uc, z_frames=torch.cat(z_list, 0), output=latents,
+              shapes={k: tuple(v.shape) for k, v in unet.state_dict().items()})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: final absmax {latents.abs().max():.4f} ({time.time() - t0:.1f}s)")
+
+
 def gen_schedule(name):
     Disc = ref_import.ref("sgm.modules.diffusionmodules.discretizer.EDMDiscretization")
     Scal = ref_import.ref("sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise")
@@ -169,6 +236,9 @@ def main():
                                                max_scale=2.0, stage=2, iseed=5),
         "vae_tiny": lambda: gen_vae("vae_tiny", 64, 2, 8),
         "vae_full_lat8": lambda: gen_vae("vae_full_lat8", 128, 1, 8, iseed=2),
+        "vae_enc_tiny": lambda: gen_vae_encode("vae_enc_tiny", 64, 2, 64),
+        "vae_enc_full_64": lambda: gen_vae_encode("vae_enc_full_64", 128, 1, 64, iseed=4),
+        "v02_tiny": lambda: gen_v02("v02_tiny", unet_cfg(2, 64), T=4, hw=8, steps=4, max_scale=2.0, iseed=6),
         "unet_s1_lat16": lambda: gen_unet("unet_s1_lat16", unet_cfg(1), T=4, hw=16, iseed=1),
         "unet_s2_lat16": lambda: gen_unet("unet_s2_lat16", unet_cfg(2), T=4, hw=16, iseed=2),
     }

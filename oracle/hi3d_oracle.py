@@ -312,3 +312,47 @@ def vae_decode(sd, dd, z, scale_factor=0.18215, prefix="first_stage_model."):
                          sd[f"{D}up.{lvl}.upsample.conv.weight"], sd[f"{D}up.{lvl}.upsample.conv.bias"], padding=1)
     h = F.silu(_gn(sd, D + "norm_out", h, 1e-6))
     return F.conv2d(h, sd[D + "conv_out.weight"], sd[D + "conv_out.bias"], padding=1)
+
+
+def vae_encode_moments(sd, dd, x, prefix="first_stage_model."):
+    """Encoder.forward (model.py:576-601) + quant_conv (models/autoencoder.py:468-476):
+    returns the posterior moments [N, 2*Cz, h, w] (mean || logvar)."""
+    P = prefix
+    E = P + "encoder."
+    h = F.conv2d(x, sd[E + "conv_in.weight"], sd[E + "conv_in.bias"], padding=1)
+    nlev = len(dd["ch_mult"])
+    for lvl in range(nlev):
+        for blk in range(dd["num_res_blocks"]):
+            h = _vae_resnet(sd, f"{E}down.{lvl}.block.{blk}", h)
+        if lvl != nlev - 1:                          # Downsample: pad (0,1,0,1) then stride-2 conv (model.py:76-90)
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"{E}down.{lvl}.downsample.conv.weight"],
+                         sd[f"{E}down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _vae_resnet(sd, E + "mid.block_1", h)
+    h = _vae_attn(sd, E + "mid.attn_1", h)
+    h = _vae_resnet(sd, E + "mid.block_2", h)
+    h = F.silu(_gn(sd, E + "norm_out", h, 1e-6))
+    h = F.conv2d(h, sd[E + "conv_out.weight"], sd[E + "conv_out.bias"], padding=1)
+    return F.conv2d(h, sd[P + "quant_conv.weight"], sd[P + "quant_conv.bias"])
+
+
+def vae_encode(sd, dd, x, noise=None, scale_factor=0.18215, prefix="first_stage_model."):
+    """encode_first_stage (models/diffusion.py:137-150): posterior sample (noise given) or mode,
+    times scale_factor.  DiagonalGaussianDistribution: distributions.py:24-41."""
+    mean, logvar = vae_encode_moments(sd, dd, x, prefix).chunk(2, dim=1)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
+    return scale_factor * z
+
+
+def v02_refine(sd, cfg, z_frames, init_noise, c, uc, T, num_steps, max_scale, alpha_pow=40.0,
+               prefix="model.diffusion_model."):
+    """The stage-2 loop of pipeline_i2v_eval_v02.py:103-135: before every Euler step the latents are
+    pulled back towards (noise*sigma_i + z) with alpha_i = (0.5(1+cos(i/num_steps)))^40."""
+    sig = edm_sigmas(num_steps)
+    scale = torch.linspace(1.0, max_scale, T)
+    lat = init_noise * torch.sqrt(1.0 + sig[0] ** 2)
+    for i in range(num_steps):
+        a = (0.5 * (1.0 + math.cos(i * 1.0 / num_steps))) ** alpha_pow
+        lat = lat * (1.0 - a) + (init_noise * sig[i] + z_frames) * a
+        d = denoise_cfg(sd, cfg, lat, sig[i], c, uc, T, scale, prefix)
+        lat = lat + (sig[i + 1] - sig[i]) * (lat - d) / sig[i]
+    return lat

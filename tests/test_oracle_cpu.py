@@ -89,3 +89,22 @@ def test_cross_attention_single_token_identity():
     vec = torch.nn.functional.linear(torch.nn.functional.linear(ctx, sd["a.to_v.weight"]), sd["a.to_out.0.weight"],
                                      sd["a.to_out.0.bias"])
     assert torch.allclose(full, vec.expand_as(full), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["vae_enc_tiny", "vae_enc_full_64"])
+def test_vae_encode_oracle_matches_reference(name):
+    fx = load(name)
+    sd = weights(fx)
+    with torch.no_grad():
+        mom = O.vae_encode_moments(sd, fx["ddconfig"], fx["x"], prefix=fx["key_prefix"])
+        z = O.vae_encode(sd, fx["ddconfig"], fx["x"], noise=fx["sample_noise"], scale_factor=1.0, prefix=fx["key_prefix"])
+    assert rel(mom, fx["moments"]) < TOL
+    assert rel(z, fx["z_sampled"]) < TOL          # reference posterior.sample() with the same CPU draw
+
+
+def test_v02_refine_oracle_matches_reference():
+    fx = load("v02_tiny")
+    with torch.no_grad():
+        out = O.v02_refine(weights(fx), fx["cfg"], fx["z_frames"], fx["init"], fx["c"], fx["uc"], fx["T"], fx["steps"],
+                           fx["max_scale"], prefix=fx["key_prefix"])
+    assert rel(out, fx["output"]) < TOL

@@ -114,3 +114,29 @@ def test_unet_vs_oracle_other_shape(dev):
     rel, cos = stats(out, ref)
     print(f"oracle shape test: rel {rel:.4f} cos {cos:.6f}")
     assert rel < 4e-2 and cos > 0.9995
+
+
+def test_stage2_refine_loop_matches_reference_golden(dev):
+    """pipeline_i2v_eval_v02.py:103-135 through hi3d_hip.pipelines.stage2_refine
+    (fused v02 blend kernel + sampler.step_call) vs the reference's loop."""
+    from types import SimpleNamespace
+    from hi3d_hip.pipelines import stage2_refine
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    fx = load("v02_tiny")
+    T = fx["T"]
+    model = SimpleNamespace(
+        device=dev, model=OpenAIWrapper(build_unet(fx, dev)),
+        denoiser=Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
+        sampler=EulerEDMSampler(
+            num_steps=fx["steps"], device=dev,
+            discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+            guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                           "params": {"num_frames": T, "max_scale": fx["max_scale"], "min_scale": 1.0}}))
+    c = {k: v.to(dev) for k, v in fx["c"].items()}
+    uc = {k: v.to(dev) for k, v in fx["uc"].items()}
+    out = stage2_refine(model, None, c, uc, init_noise=fx["init"], decode=False, z_frames=fx["z_frames"])
+    rel, cos = stats(out, fx["output"])
+    print(f"v02 loop: rel {rel:.4f} cos {cos:.6f}")
+    assert rel < 6e-2 and cos > 0.999

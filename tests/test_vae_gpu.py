@@ -43,3 +43,42 @@ def test_engine_decode_first_stage_chunks(dev):
     out = eng.decode_first_stage(fx["z"].to(dev)).float().cpu()
     rel = ((out - fx["output"]).abs().max() / fx["output"].abs().max()).item()
     assert rel < 4e-2
+
+
+@pytest.mark.parametrize("name", ["vae_enc_tiny", "vae_enc_full_64"])
+def test_vae_encode_matches_reference_golden(dev, name):
+    """Encoder + quant_conv + posterior: mode vs the reference mean, and sample with the
+    reference's own CPU noise draw vs its posterior.sample()."""
+    from hi3d_hip import synth
+    from sgm.models.autoencoder import AutoencoderKL, AutoencoderKLModeOnly
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    ae = AutoencoderKL(embed_dim=4, ddconfig=fx["ddconfig"])
+    synth.fill_module_(ae, fx["weight_seed"], prefix=fx["key_prefix"])
+    ae = ae.to(dev)
+    mean_ref = fx["moments"][:, :4]
+    z = ae.encode(fx["x"].to(dev), noise=fx["sample_noise"]).float().cpu()
+    rel_s = ((z - fx["z_sampled"]).abs().max() / fx["z_sampled"].abs().max()).item()
+    mo = AutoencoderKLModeOnly(embed_dim=4, ddconfig=fx["ddconfig"])
+    synth.fill_module_(mo, fx["weight_seed"], prefix=fx["key_prefix"])
+    zm = mo.to(dev).encode(fx["x"].to(dev)).float().cpu()
+    rel_m = ((zm - mean_ref).abs().max() / mean_ref.abs().max()).item()
+    print(f"{name}: sample rel {rel_s:.4f}  mode rel {rel_m:.4f}")
+    assert rel_s < 4e-2 and rel_m < 4e-2
+    torch.manual_seed(1234)                       # default path draws the posterior noise on the CPU generator, like the reference
+    z2 = ae.encode(fx["x"].to(dev)).float().cpu()
+    assert torch.equal(z2, z)
+
+
+def test_conv3x3_bottom_right_padding(dev):
+    import torch.nn.functional as F
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 64, 10, 12), generator=g).to(torch.bfloat16)
+    w = (torch.randn((128, 64, 3, 3), generator=g) * (576 ** -0.5)).to(torch.bfloat16).float()
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w, stride=2)
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, 64)
+    out = ops.gemm(xt.to(dev), pack_conv3x3(w).to(dev), M=2 * 5 * 6, N=128, K=576,
+                   conv3x3=dict(Hin=10, Win=12, Cin=64, Hout=5, Wout=6, stride=2, up2x=0, pad_br_only=1))
+    got = out.float().cpu().reshape(2, 5, 6, 128).permute(0, 3, 1, 2)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 1.2e-2
