@@ -177,6 +177,26 @@ __global__ void v02_blend_kernel(float* __restrict__ lat, const float* __restric
     lat[i] = lat[i] * (1.0f - alpha) + (noise[i] * sigma + z[i]) * alpha;
 }
 
+__global__ void time_mix_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                      const float* __restrict__ b, float* __restrict__ out, int T, int HW,
+                                      int C, int ldx, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;    // over (b t) * HW
+  if (idx >= total) return;
+  const int p = (int)(idx % HW); const long f = idx / HW; const int t = (int)(f % T);
+  float acc[4];
+  for (int co = 0; co < C; ++co) acc[co] = b[co];
+  for (int kt = 0; kt < 3; ++kt) {
+    const int tt = t + kt - 1;
+    if (tt < 0 || tt >= T) continue;
+    const float* xp = x + (idx + (long)(kt - 1) * HW) * ldx;
+    for (int ci = 0; ci < C; ++ci) {
+      const float v = xp[ci];
+      for (int co = 0; co < C; ++co) acc[co] += w[(co * C + ci) * 3 + kt] * v;
+    }
+  }
+  for (int co = 0; co < C; ++co) out[(f * C + co) * HW + p] = acc[co];
+}
+
 inline unsigned grid_for(long n, int block, long cap = 65536) {
   long g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -306,6 +326,17 @@ extern "C" int hi3d_v02_blend(float* lat, const float* noise, const float* z, in
   if (!lat || !noise || !z) HI3D_FAIL(HI3D_EINVAL, "v02_blend: null pointer");
   if (n <= 0) HI3D_FAIL(HI3D_EINVAL, "v02_blend: non-positive size");
   hipLaunchKernelGGL(v02_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, lat, noise, z, (long)n, alpha, sigma);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_time_mix_small(const float* x, const float* w, const float* b, float* out, int32_t B,
+                                   int32_t T, int32_t HW, int32_t C, int32_t ldx, void* stream) {
+  if (!x || !w || !b || !out) HI3D_FAIL(HI3D_EINVAL, "time_mix_small: null pointer");
+  if (B <= 0 || T <= 0 || HW <= 0 || C <= 0 || C > 4 || ldx < C) HI3D_FAIL(HI3D_EINVAL, "time_mix_small: bad size");
+  const long total = (long)B * T * HW;
+  hipLaunchKernelGGL(time_mix_small_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, w, b, out, T, HW, C, ldx, total);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -281,3 +281,10 @@ def v02_blend(lat, noise, z, alpha, sigma):
             raise _l.Hi3dError("v02_blend: fp32 contiguous tensors required")
     _l.check(_lib.hi3d_v02_blend(_p(lat), _p(noise), _p(z), lat.numel(), float(alpha), float(sigma), _stream()), "hi3d_v02_blend")
     return lat
+
+
+def time_mix_small(x, w, b, B, T, H, W, C):
+    """x fp32 [(B*T*H*W), ldx] -> fp32 NCHW [B*T, C, H, W]: Conv3d (3,1,1) over the frame axis."""
+    out = torch.empty((B * T, C, H, W), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_time_mix_small(_p(x), _p(w), _p(b), _p(out), B, T, H * W, C, x.stride(0), _stream()), "hi3d_time_mix_small")
+    return out

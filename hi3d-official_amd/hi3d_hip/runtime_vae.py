@@ -37,8 +37,11 @@ class VAEDecoderRuntime:
         f32 = lambda k: pack.f32(g(k))
         W = {}
         zc = self.dd["z_channels"]
-        W["pq.w"] = f32("post_quant_conv.weight").reshape(zc, -1).contiguous()
-        W["pq.b"] = f32("post_quant_conv.bias")
+        if (P + "post_quant_conv.weight") in sd:
+            W["pq.w"] = f32("post_quant_conv.weight").reshape(zc, -1).contiguous()
+            W["pq.b"] = f32("post_quant_conv.bias")
+        else:                                   # AutoencodingEngine (SVD-style) has no quant convs
+            W["pq.w"] = torch.eye(zc, device=dev); W["pq.b"] = torch.zeros(zc, device=dev)
         D = "decoder."
         W["conv_in.w"] = pack.pack_conv3x3(g(D + "conv_in.weight"), cin_pad=CZ_PAD); W["conv_in.b"] = f32(D + "conv_in.bias")
 
@@ -125,6 +128,9 @@ class VAEDecoderRuntime:
         h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6)
         ocp = W["conv_out.b"].numel()
         out = self._conv(h, "conv_out", N, H, Wd, cin, ocp, out_fp32=True)
+        return self._finish(out, N, H, Wd, ocp)
+
+    def _finish(self, out, N, H, Wd, ocp):
         return ops.tokens_to_nchw(out, N, self.out_ch, H, Wd, ocp)
 
 
@@ -211,3 +217,61 @@ class VAEEncoderRuntime(_ResnetMixin):
         if noise is not None:
             noise = noise.to(self.dev, torch.float32).contiguous()
         return ops.vae_posterior(mom, W["q.w"], W["q.b"], noise, N, self.zc, H, Wd)
+
+
+class VideoDecoderRuntime(VAEDecoderRuntime):
+    """Temporal VAE decoder, time_mode 'conv-only' with video_kernel_size [3,1,1]
+    (sgm/modules/autoencoding/temporal_ae.py:18-107,293-349; hooked in by
+    DiffusionEngine.decode_first_stage, models/diffusion.py:126-129).  Every ResnetBlock is
+    followed by a temporal ResBlock (GroupNorm over t,h,w -> SiLU -> Conv3d (3,1,1), twice,
+    no timestep embedding) blended in as x_s + sigmoid(mix_factor) * h_t, and conv_out is
+    followed by a 3-channel Conv3d (3,1,1).  Same kernels as the UNet's time_stack: the frame
+    axis is indexed inside the conv / norm kernels, nothing is permuted."""
+
+    def __init__(self, state_dict, ddconfig, device, prefix=""):
+        super().__init__(state_dict, ddconfig, device, prefix)
+        dev, sd, P = self.dev, state_dict, prefix
+        g = lambda k: sd[P + k].detach().to(dev)
+        f32 = lambda k: pack.f32(g(k))
+        D = "decoder."
+        W = self.W
+        names = ["mid.block_1", "mid.block_2"] + [f"up.{l}.block.{b}" for l in range(len(self.mult)) for b in range(self.nres + 1)]
+        for p in names:
+            q = p + ".time_stack"
+            for n in ("in_layers.0", "out_layers.0"):
+                W[f"{q}.{n}.g"] = f32(f"{D}{q}.{n}.weight"); W[f"{q}.{n}.b"] = f32(f"{D}{q}.{n}.bias")
+            for n in ("in_layers.2", "out_layers.3"):
+                W[f"{q}.{n}.w"] = pack.pack_convt3(g(f"{D}{q}.{n}.weight")); W[f"{q}.{n}.b"] = f32(f"{D}{q}.{n}.bias")
+            W[p + ".alpha"] = torch.sigmoid(g(f"{D}{p}.mix_factor").float()).reshape(1)
+        oc = self.out_ch
+        W["tmix.w"] = f32(D + "conv_out.time_mix_conv.weight").reshape(oc, oc, 3).contiguous()
+        W["tmix.b"] = f32(D + "conv_out.time_mix_conv.bias")
+        self._T = None
+
+    def _resnet(self, p, x, N, H, Wd, Cin, Cout):
+        xs = super()._resnet(p, x, N, H, Wd, Cin, Cout)
+        W, T, HW = self.W, self._T, H * Wd
+        B = N // T
+        q = p + ".time_stack"
+        tg = dict(T=T, HW=HW, Cin=Cout)
+        h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5)
+        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"], convt3=tg)
+        h = ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], B, T * HW, Cout, 1e-5)
+        a1 = W[p + ".alpha"].expand(N).contiguous()
+        # alpha*(x_s + h_t) + (1-alpha)*x_s == x_s + alpha*h_t          (temporal_ae.py:72-79)
+        return ops.gemm(h, W[q + ".out_layers.3.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
+                        a1=a1, R2=xs, rows_per_group=HW, convt3=tg)
+
+    @torch.no_grad()
+    def decode(self, z, timesteps=None):
+        N = z.shape[0]
+        T = N if timesteps is None else int(timesteps)
+        if N % T:
+            raise ops._l.Hi3dError("VideoDecoder: batch is not a multiple of timesteps")
+        self._T = T
+        self._defer_out = True
+        return super().decode(z)
+
+    def _finish(self, out, N, H, Wd, ocp):
+        # conv_out's 2-D result (fp32 [N*H*W, ocp]) -> time_mix_conv -> NCHW
+        return ops.time_mix_small(out, self.W["tmix.w"], self.W["tmix.b"], N // self._T, self._T, H, Wd, self.out_ch)

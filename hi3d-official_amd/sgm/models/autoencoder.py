@@ -8,58 +8,90 @@ import torch
 from ..util import ParamTree
 
 
-def vae_param_shapes(dd, embed_dim):
-    ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
-    if dd.get("attn_resolutions"):
-        raise NotImplementedError("attn_resolutions must be empty (only the mid-block attention exists in Hi3D)")
-    S = {}
-
-    def conv(p, o, i, k):
-        S[p + ".weight"] = (o, i, k, k); S[p + ".bias"] = (o,)
+def _shape_helpers(S):
+    def conv(p, o, i, *k):
+        S[p + ".weight"] = (o, i) + tuple(k); S[p + ".bias"] = (o,)
 
     def norm(p, c):
         S[p + ".weight"] = (c,); S[p + ".bias"] = (c,)
 
-    def resnet(p, cin, cout):
-        norm(p + ".norm1", cin); conv(p + ".conv1", cout, cin, 3)
-        norm(p + ".norm2", cout); conv(p + ".conv2", cout, cout, 3)
+    def resnet(p, cin, cout, temporal=False):
+        norm(p + ".norm1", cin); conv(p + ".conv1", cout, cin, 3, 3)
+        norm(p + ".norm2", cout); conv(p + ".conv2", cout, cout, 3, 3)
         if cin != cout:
-            conv(p + ".nin_shortcut", cout, cin, 1)
+            conv(p + ".nin_shortcut", cout, cin, 1, 1)
+        if temporal:        # VideoResBlock (temporal_ae.py:18-81): ResBlock(dims=3, skip_t_emb) + mix_factor
+            q = p + ".time_stack"
+            norm(q + ".in_layers.0", cout); conv(q + ".in_layers.2", cout, cout, 3, 1, 1)
+            norm(q + ".out_layers.0", cout); conv(q + ".out_layers.3", cout, cout, 3, 1, 1)
+            S[p + ".mix_factor"] = (1,)
 
-    def mid(p, c):
-        resnet(p + ".block_1", c, c)
+    def mid(p, c, temporal=False):
+        resnet(p + ".block_1", c, c, temporal)
         norm(p + ".attn_1.norm", c)
         for n in ("q", "k", "v", "proj_out"):
-            conv(f"{p}.attn_1.{n}", c, c, 1)
-        resnet(p + ".block_2", c, c)
+            conv(f"{p}.attn_1.{n}", c, c, 1, 1)
+        resnet(p + ".block_2", c, c, temporal)
+    return conv, norm, resnet, mid
 
-    # encoder (model.py:487-575)
-    conv("encoder.conv_in", ch, dd["in_channels"], 3)
+
+def _check_dd(dd):
+    if dd.get("attn_resolutions"):
+        raise NotImplementedError("attn_resolutions must be empty (only the mid-block attention exists in Hi3D)")
+    if dd.get("attn_type", "vanilla") not in ("vanilla", "vanilla-xformers"):
+        raise NotImplementedError(f"attn_type {dd.get('attn_type')}")
+
+
+def encoder_param_shapes(dd, prefix="encoder."):
+    """Encoder (reference sgm/modules/diffusionmodules/model.py:487-575)."""
+    _check_dd(dd)
+    ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
+    S = {}
+    conv, norm, resnet, mid = _shape_helpers(S)
+    conv(prefix + "conv_in", ch, dd["in_channels"], 3, 3)
     in_mult = [1] + mult
     for lvl in range(len(mult)):
         cin, cout = ch * in_mult[lvl], ch * mult[lvl]
         for b in range(nres):
-            resnet(f"encoder.down.{lvl}.block.{b}", cin, cout); cin = cout
+            resnet(f"{prefix}down.{lvl}.block.{b}", cin, cout); cin = cout
         if lvl != len(mult) - 1:
-            conv(f"encoder.down.{lvl}.downsample.conv", cout, cout, 3)
+            conv(f"{prefix}down.{lvl}.downsample.conv", cout, cout, 3, 3)
     top = ch * mult[-1]
-    mid("encoder.mid", top)
-    norm("encoder.norm_out", top)
-    conv("encoder.conv_out", 2 * zc if dd.get("double_z", True) else zc, top, 3)
-    # decoder (model.py:604-714)
-    conv("decoder.conv_in", top, zc, 3)
-    mid("decoder.mid", top)
+    mid(prefix + "mid", top)
+    norm(prefix + "norm_out", top)
+    conv(prefix + "conv_out", 2 * zc if dd.get("double_z", True) else zc, top, 3, 3)
+    return S
+
+
+def decoder_param_shapes(dd, prefix="decoder.", temporal=False):
+    """Decoder (model.py:604-714) / VideoDecoder 'conv-only' (temporal_ae.py:293-349)."""
+    _check_dd(dd)
+    ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
+    S = {}
+    conv, norm, resnet, mid = _shape_helpers(S)
+    top = ch * mult[-1]
+    conv(prefix + "conv_in", top, zc, 3, 3)
+    mid(prefix + "mid", top, temporal)
     cin = top
     for lvl in reversed(range(len(mult))):
         cout = ch * mult[lvl]
         for b in range(nres + 1):
-            resnet(f"decoder.up.{lvl}.block.{b}", cin, cout); cin = cout
+            resnet(f"{prefix}up.{lvl}.block.{b}", cin, cout, temporal); cin = cout
         if lvl != 0:
-            conv(f"decoder.up.{lvl}.upsample.conv", cout, cout, 3)
-    norm("decoder.norm_out", cin)
-    conv("decoder.conv_out", dd["out_ch"], cin, 3)
-    conv("quant_conv", (1 + dd.get("double_z", True)) * embed_dim, (1 + dd.get("double_z", True)) * zc, 1)
-    conv("post_quant_conv", zc, embed_dim, 1)
+            conv(f"{prefix}up.{lvl}.upsample.conv", cout, cout, 3, 3)
+    norm(prefix + "norm_out", cin)
+    conv(prefix + "conv_out", dd["out_ch"], cin, 3, 3)
+    if temporal:                                  # AE3DConv.time_mix_conv (temporal_ae.py:84-107)
+        conv(prefix + "conv_out.time_mix_conv", dd["out_ch"], dd["out_ch"], 3, 1, 1)
+    return S
+
+
+def vae_param_shapes(dd, embed_dim):
+    zc, dz = dd["z_channels"], 1 + bool(dd.get("double_z", True))
+    S = {}
+    S.update(encoder_param_shapes(dd)); S.update(decoder_param_shapes(dd))
+    S["quant_conv.weight"] = (dz * embed_dim, dz * zc, 1, 1); S["quant_conv.bias"] = (dz * embed_dim,)
+    S["post_quant_conv.weight"] = (zc, embed_dim, 1, 1); S["post_quant_conv.bias"] = (zc,)
     return S
 
 
@@ -125,3 +157,51 @@ class AutoencoderKL(ParamTree):
 
 class AutoencoderKLModeOnly(AutoencoderKL):
     sample_posterior = False
+
+
+class AutoencodingEngine(torch.nn.Module):
+    """Generic autoencoder wrapper (reference models/autoencoder.py:96-250, inference surface):
+    `encoder_config` / `decoder_config` name Encoder / Decoder / VideoDecoder; no quant convs.
+    This is how the north_star's temporal decoder (sgm.modules.autoencoding.temporal_ae.VideoDecoder)
+    is wired in SVD-style configs; DiffusionEngine.decode_first_stage passes `timesteps`."""
+
+    def __init__(self, *args, encoder_config, decoder_config, loss_config=None, regularizer_config=None,
+                 optimizer_config=None, lr_g_factor=1.0, ckpt_path=None, **kwargs):
+        super().__init__()
+        from ..util import instantiate_from_config
+        self.encoder = instantiate_from_config(encoder_config)
+        self.decoder = instantiate_from_config(decoder_config)
+        self.sample_posterior = True
+        if regularizer_config is not None:
+            self.sample_posterior = bool((regularizer_config.get("params") or {}).get("sample", True))
+        self._dec_rt = self._enc_rt = None
+        self._dec_key = self._enc_key = None
+        if ckpt_path is not None:
+            from safetensors.torch import load_file
+            sd = load_file(ckpt_path) if ckpt_path.endswith("safetensors") else torch.load(ckpt_path, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+
+    @property
+    def is_video_decoder(self):
+        return getattr(self.decoder, "temporal", False)
+
+    def _key(self, device):
+        p0 = next(self.parameters())
+        return (torch.device(device), p0.data_ptr(), p0._version, p0.dtype)
+
+    @torch.no_grad()
+    def decode(self, z, **kwargs):
+        if not z.is_cuda:
+            raise RuntimeError("decode runs on the MI355X only (no CPU path in this framework)")
+        from hi3d_hip.runtime_vae import VAEDecoderRuntime, VideoDecoderRuntime
+        key = self._key(z.device)
+        if self._dec_rt is None or self._dec_key != key:
+            cls = VideoDecoderRuntime if self.is_video_decoder else VAEDecoderRuntime
+            self._dec_rt, self._dec_key = cls(self.state_dict(), self.decoder.ddconfig, z.device), key
+        if self.is_video_decoder:
+            return self._dec_rt.decode(z, timesteps=kwargs.get("timesteps")).to(z.dtype)
+        return self._dec_rt.decode(z).to(z.dtype)
+
+    @torch.no_grad()
+    def encode(self, x, return_reg_log=False, unregularized=False, noise=None):
+        raise NotImplementedError("AutoencodingEngine.encode: use AutoencoderKL (the encoder runtime expects quant_conv)")

@@ -242,6 +242,13 @@ int hi3d_vae_posterior(const float* mom, const float* wq, const float* bq, const
 int hi3d_v02_blend(float* lat, const float* noise, const float* z, int64_t n, float alpha,
                    float sigma, void* stream);
 
+/* AE3DConv's time_mix_conv on the 3 output channels of the temporal VAE decoder
+ * (sgm/modules/autoencoding/temporal_ae.py:84-107): Conv3d (3,1,1), padding (1,0,0), C <= 4:
+ *   out[f][co][p] = b[co] + sum_{kt,ci} w[co][ci][kt] * x[f + kt - 1][p][ci]   (inside the clip)
+ * x: fp32 channels-last [(b t)*HW][ldx] ; out: fp32 NCHW [(b t)][C][HW].               */
+int hi3d_time_mix_small(const float* x, const float* w, const float* b, float* out, int32_t B,
+                        int32_t T, int32_t HW, int32_t C, int32_t ldx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

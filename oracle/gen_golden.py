@@ -207,6 +207,27 @@ def gen_v02(name, cfg, T, hw, steps, max_scale, wseed=1, iseed=0):
     print(f"{name}: final absmax {latents.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
 
+def gen_video_decode(name, ch, b, T, hw, wseed=1, iseed=0):
+    t0 = time.time()
+    AE = ref_import.ref("sgm.models.autoencoder.AutoencodingEngine")
+    dd = vae_ddconfig(ch)
+    ae = AE(encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+            decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
+                            "params": dict(dd, video_kernel_size=[3, 1, 1])},
+            loss_config={"target": "torch.nn.Identity"},
+            regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"}).eval()
+    synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
+    g = torch.Generator().manual_seed(iseed)
+    z = torch.randn((b * T, 4, hw, hw), generator=g)
+    with torch.no_grad():
+        out = ae.decode(z, timesteps=T)
+    sd = ae.state_dict()
+    fx = dict(kind="video_decode", ddconfig=dd, T=T, weight_seed=wseed, key_prefix=VAE_PREFIX, z=z, output=out,
+              shapes={k: tuple(v.shape) for k, v in sd.items()})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
+
+
 def gen_schedule(name):
     Disc = ref_import.ref("sgm.modules.diffusionmodules.discretizer.EDMDiscretization")
     Scal = ref_import.ref("sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise")
@@ -238,6 +259,8 @@ def main():
         "vae_full_lat8": lambda: gen_vae("vae_full_lat8", 128, 1, 8, iseed=2),
         "vae_enc_tiny": lambda: gen_vae_encode("vae_enc_tiny", 64, 2, 64),
         "vae_enc_full_64": lambda: gen_vae_encode("vae_enc_full_64", 128, 1, 64, iseed=4),
+        "videodec_tiny": lambda: gen_video_decode("videodec_tiny", 64, 2, 3, 8),
+        "videodec_full_lat8": lambda: gen_video_decode("videodec_full_lat8", 128, 1, 4, 8, iseed=3),
         "v02_tiny": lambda: gen_v02("v02_tiny", unet_cfg(2, 64), T=4, hw=8, steps=4, max_scale=2.0, iseed=6),
         "unet_s1_lat16": lambda: gen_unet("unet_s1_lat16", unet_cfg(1), T=4, hw=16, iseed=1),
         "unet_s2_lat16": lambda: gen_unet("unet_s2_lat16", unet_cfg(2), T=4, hw=16, iseed=2),

@@ -356,3 +356,40 @@ def v02_refine(sd, cfg, z_frames, init_noise, c, uc, T, num_steps, max_scale, al
         d = denoise_cfg(sd, cfg, lat, sig[i], c, uc, T, scale, prefix)
         lat = lat + (sig[i + 1] - sig[i]) * (lat - d) / sig[i]
     return lat
+
+
+def video_decode(sd, dd, z, T, prefix="first_stage_model."):
+    """VideoDecoder.forward, time_mode 'conv-only', video_kernel_size [3,1,1]
+    (temporal_ae.py:18-107,293-349 on top of Decoder.forward model.py:715-748); z already divided
+    by scale_factor; no post_quant_conv (AutoencodingEngine)."""
+    D = prefix + "decoder."
+    n = z.shape[0]
+    b = n // T
+
+    def vres(p, x):
+        x = _vae_resnet(sd, p, x)
+        c, hh, ww = x.shape[1:]
+        x5 = x.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)
+        q = p + ".time_stack"          # ResBlock(dims=3, skip_t_emb=True): openaimodel.py:328-354 without emb
+        h = F.conv3d(F.silu(_gn(sd, q + ".in_layers.0", x5, 1e-5)), sd[q + ".in_layers.2.weight"], sd[q + ".in_layers.2.bias"], padding=(1, 0, 0))
+        h = F.conv3d(F.silu(_gn(sd, q + ".out_layers.0", h, 1e-5)), sd[q + ".out_layers.3.weight"], sd[q + ".out_layers.3.bias"], padding=(1, 0, 0))
+        a = torch.sigmoid(sd[p + ".mix_factor"])
+        out = a * (x5 + h) + (1.0 - a) * x5
+        return out.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+
+    h = F.conv2d(z, sd[D + "conv_in.weight"], sd[D + "conv_in.bias"], padding=1)
+    h = vres(D + "mid.block_1", h)
+    h = _vae_attn(sd, D + "mid.attn_1", h)
+    h = vres(D + "mid.block_2", h)
+    for lvl in reversed(range(len(dd["ch_mult"]))):
+        for blk in range(dd["num_res_blocks"] + 1):
+            h = vres(f"{D}up.{lvl}.block.{blk}", h)
+        if lvl != 0:
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"),
+                         sd[f"{D}up.{lvl}.upsample.conv.weight"], sd[f"{D}up.{lvl}.upsample.conv.bias"], padding=1)
+    h = F.silu(_gn(sd, D + "norm_out", h, 1e-6))
+    h = F.conv2d(h, sd[D + "conv_out.weight"], sd[D + "conv_out.bias"], padding=1)          # AE3DConv: 2-D conv ...
+    c, hh, ww = h.shape[1:]
+    h5 = h.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)                                   # ... then time_mix_conv
+    h5 = F.conv3d(h5, sd[D + "conv_out.time_mix_conv.weight"], sd[D + "conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
+    return h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)

@@ -145,3 +145,19 @@ def test_create_model_from_yaml_builds_engine():
     assert any(k.startswith("first_stage_model.decoder.conv_in.weight") for k in keys)
     assert m.num_samples == 16 and m.sampler.num_steps == 25 and m.sampler.guider.max_scale == 2.5
     assert abs(m.scale_factor - 0.18215) < 1e-9 and m.en_and_decode_n_samples_a_time == 16
+
+
+def test_autoencoding_engine_video_decoder_state_dict_matches_reference():
+    from sgm.models.autoencoder import AutoencodingEngine
+    fx = load("videodec_tiny")
+    dd = fx["ddconfig"]
+    ae = AutoencodingEngine(
+        encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(dd, video_kernel_size=[3, 1, 1])},
+        loss_config={"target": "torch.nn.Identity"},
+        regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"})
+    assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == fx["shapes"]
+    assert ae.is_video_decoder
+    from sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    with pytest.raises(NotImplementedError, match="time_mode"):
+        VideoDecoder(**dd, video_kernel_size=[3, 1, 1], time_mode="all")

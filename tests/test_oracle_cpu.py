@@ -108,3 +108,11 @@ def test_v02_refine_oracle_matches_reference():
         out = O.v02_refine(weights(fx), fx["cfg"], fx["z_frames"], fx["init"], fx["c"], fx["uc"], fx["T"], fx["steps"],
                            fx["max_scale"], prefix=fx["key_prefix"])
     assert rel(out, fx["output"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8"])
+def test_video_decoder_oracle_matches_reference(name):
+    fx = load(name)
+    with torch.no_grad():
+        out = O.video_decode(weights(fx), fx["ddconfig"], fx["z"], fx["T"], prefix=fx["key_prefix"])
+    assert rel(out, fx["output"]) < TOL

@@ -82,3 +82,31 @@ def test_conv3x3_bottom_right_padding(dev):
                    conv3x3=dict(Hin=10, Win=12, Cin=64, Hout=5, Wout=6, stride=2, up2x=0, pad_br_only=1))
     got = out.float().cpu().reshape(2, 5, 6, 128).permute(0, 3, 1, 2)
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1.2e-2
+
+
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8"])
+def test_video_decoder_matches_reference_golden(dev, name):
+    """Temporal VAE decoder (north_star's 'AutoencoderKLTemporalDecoder' = VideoDecoder) through
+    AutoencodingEngine + the DiffusionEngine.decode_first_stage `timesteps` hook."""
+    from hi3d_hip import synth
+    from sgm.models.autoencoder import AutoencodingEngine
+    from sgm.models.diffusion import DiffusionEngine
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    dd = fx["ddconfig"]
+    ae = AutoencodingEngine(
+        encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(dd, video_kernel_size=[3, 1, 1])},
+        regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"})
+    synth.fill_module_(ae, fx["weight_seed"], prefix=fx["key_prefix"])
+    ae = ae.to(dev)
+    out = ae.decode(fx["z"].to(dev), timesteps=fx["T"]).float().cpu()
+    ref = fx["output"]
+    rel = ((out - ref).abs().max() / ref.abs().max()).item()
+    psnr = 10 * math.log10(ref.abs().max().item() ** 2 / ((out - ref) ** 2).mean().item())
+    print(f"{name}: rel {rel:.4f} psnr {psnr:.1f} dB")
+    assert rel < 4e-2 and psnr > 35.0
+    eng = DiffusionEngine.__new__(DiffusionEngine)
+    torch.nn.Module.__init__(eng)
+    eng.first_stage_model, eng.scale_factor, eng.en_and_decode_n_samples_a_time = ae, 0.5, fx["T"]
+    out2 = eng.decode_first_stage(fx["z"].to(dev) * 0.5).float().cpu()          # chunk of T frames -> timesteps=T
+    assert ((out2 - ref).abs().max() / ref.abs().max()).item() < 4e-2
