@@ -48,8 +48,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["s1", "s2"], default="s2")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,12 +81,15 @@ def main():
     lat = 64 if stage == 1 else 128
     cfg = unet_cfg(stage)
     t0 = time.time()
-    unet = VideoUNet(**cfg)
-    synth.fill_module_(unet, seed=1, prefix="model.diffusion_model.")
+    from sgm.util import ParamTree
+    ParamTree.skip_init = True                       # random-init weights are drawn on the device below
+    with torch.device(dev):
+        unet = VideoUNet(**cfg)
+    ParamTree.skip_init = False
+    synth.fill_module_on_device_(unet, seed=1, prefix="model.diffusion_model.")
     cpu_sd = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_sd = {"model.diffusion_model." + k: v.clone() for k, v in unet.state_dict().items()}
-    unet = unet.to(dev)
+        cpu_sd = {"model.diffusion_model." + k: v.float().cpu() for k, v in unet.state_dict().items()}
     model = OpenAIWrapper(unet)
     unet.runtime(dev)                      # one-time weight re-layout
     log(f"[bench] rank {rank}: model built + packed in {time.time() - t0:.1f}s")

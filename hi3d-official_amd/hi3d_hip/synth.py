@@ -41,6 +41,27 @@ def synth_state_dict(shapes: dict, seed: int = 1) -> dict:
     return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
 
 
+def fill_module_on_device_(module: torch.nn.Module, seed: int = 1, prefix: str = "") -> None:
+    """Benchmark-only variant: same per-key distributions as `synth_tensor`, drawn with the
+    DEVICE generator directly into the parameters (no 6 GB host round trip per rank).  Values
+    differ from the CPU stream, so parity tests never use this."""
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            g = torch.Generator(device=v.device)
+            g.manual_seed((zlib.crc32((prefix + k).encode()) * 2654435761 + seed * 1000003) & 0x7FFFFFFFFFFF)
+            v.normal_(generator=g)
+            if k.endswith("mix_factor"):
+                v.mul_(0.75).add_(0.5)
+            elif v.ndim >= 2:
+                v.mul_(float(v[0].numel()) ** -0.5)
+            elif k.endswith("weight"):
+                v.mul_(0.1).add_(1.0)
+            else:
+                v.mul_(0.05)
+
+
 def fill_module_(module: torch.nn.Module, seed: int = 1, prefix: str = "") -> None:
     """Overwrite every parameter/buffer of `module` in place (keys = state_dict keys)."""
     sd = module.state_dict()

@@ -63,6 +63,10 @@ class ParamTree(torch.nn.Module):
     state_dict reproduces a reference layout without reproducing the reference's module
     classes.  The compute lives in hi3d_hip runtimes that read the parameters."""
 
+    # set to True to allocate parameters without initialising them (a checkpoint / synthetic
+    # fill follows anyway; saves touching 1.5 B floats on the host)
+    skip_init = False
+
     def __init__(self, shapes=None, init=None):
         super().__init__()
         for key, shape in (shapes or {}).items():
@@ -75,7 +79,8 @@ class ParamTree(torch.nn.Module):
                 node.add_module(part, ParamTree())
             node = node._modules[part]
         t = torch.empty(tuple(shape))
-        (init or _default_init)(key, t)
+        if not ParamTree.skip_init:
+            (init or _default_init)(key, t)
         node.register_parameter(parts[-1], torch.nn.Parameter(t, requires_grad=False))
 
 

@@ -102,7 +102,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "one"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -129,3 +129,18 @@ def bench_one():
 
 if len(sys.argv) > 1 and sys.argv[1] == "one":
     bench_one()
+
+
+def bench_attn_one():
+    """kbench.py attn1 B H S : one spatial-attention shape (for rocprofv3 --pmc)."""
+    B, H, S = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    C = H * 64
+    qkv = rb(B * S, 3 * C)
+    vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+    out = torch.empty((B * S, C), device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, 0.125, out=out), iters=3, warm=1)
+    print(f"attn B={B} H={H} S={S}: {ms:.3f} ms {4.0 * B * H * S * S * 64 / ms / 1e9:.1f} TFLOP/s")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "attn1":
+    bench_attn_one()
