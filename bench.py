@@ -65,7 +65,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in this framework)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torchrun
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -116,7 +117,7 @@ def main():
         return sampler.step_call(denoiser, x, i % n_sched, s_in, sigmas, num_sigmas, cond, ucond)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
 
     for i in range(a.warmup):
@@ -132,7 +133,7 @@ def main():
     ops.PROFILER = None
     if not torch.isfinite(x).all():
         raise SystemExit("non-finite latents after the timed steps")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
@@ -202,7 +203,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -189,11 +189,17 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
 
   const int nk = p.K / BK;
-  issue(0, 0);
+  if (NS != 1) issue(0, 0);
   if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (NS == 3) {
+    if (NS == 1) {
+      // single stage, 36-40 KiB LDS: 3 blocks per CU hide each other's loads and epilogues
+      if (kt) __syncthreads();                // everyone is done reading the stage
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else if (NS == 3) {
       // stage kt must have landed; the LDS-DMA of stage kt+1 (>= LPS_MIN ops per wave) may stay in flight
       if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS_MIN) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
     }
     if (NS == 3) st = (st == 2) ? 0 : st + 1;
-    else st ^= 1;
+    else if (NS == 2) st ^= 1;
   }
 
   // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
@@ -231,18 +237,21 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   // stores) is issued row-contiguous, 16 bytes per lane.
   constexpr int BN_OUT = (EPI == HI3D_EPI_GEGLU) ? BN / 2 : BN;
   constexpr int LROW = BN_OUT * 4 + 16;            // bytes; +16 spreads ds_write_b128 lanes over banks
-  constexpr int HR = BM / 2;                       // rows per half tile
+  constexpr int MPP = (NS == 1) ? 1 : 2;           // 16-row accumulator blocks per wave and pass
+  constexpr int NPASS = 4 / MPP;
+  constexpr int HR = WM * 16 * MPP;                // rows per pass (fits the ring: checked below)
+  static_assert(HR * LROW <= NS * STAGE, "epilogue slab does not fit the LDS ring");
   constexpr int CPR = BN_OUT / 8;                  // 8-column chunks per row
   constexpr int NTHR = NW * 64;
   const int n0_out = (EPI == HI3D_EPI_GEGLU) ? n0 / 2 : n0;
   const int N_out = (EPI == HI3D_EPI_GEGLU) ? p.N / 2 : p.N;
   __syncthreads();                                 // every wave is done with the operand ring
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NPASS; ++half) {
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
-      const int mt = half * 2 + mh;
-      char* trow = smem + (wm * 32 + mh * 16 + fr) * LROW;
+    for (int mh = 0; mh < MPP; ++mh) {
+      const int mt = half * MPP + mh;
+      char* trow = smem + (wm * 16 * MPP + mh * 16 + fr) * LROW;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cl = wn * 16 * NT + fg * 4 * NT + nt * 4;    // tile-local column of acc[mt][nt][0]
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
     __syncthreads();
     for (int c = tid; c < HR * CPR; c += NTHR) {
       const int lr = c / CPR, c8 = c - lr * CPR;
-      const int m = m0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+      const int m = m0 + (lr / (16 * MPP)) * 64 + half * 16 * MPP + (lr % (16 * MPP));
       const int n = n0_out + c8 * 8;
       if (m >= p.M || n >= N_out) continue;
       const char* tp = smem + lr * LROW + c8 * 32;
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
         }
       }
     }
-    if (half == 0) __syncthreads();
+    if (half + 1 < NPASS) __syncthreads();
   }
 #endif
 }
@@ -415,10 +424,12 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (tile == 160) {
     if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
     if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);
+    if (variant == 3) return dispatch<2, 5, 1>(p, d->amode, d->epi, s);
     return dispatch<2, 5, 2>(p, d->amode, d->epi, s);
   }
   if (variant == 2) return dispatch<4, 4, 3>(p, d->amode, d->epi, s);
   if (variant == 1) return dispatch<2, 4, 3>(p, d->amode, d->epi, s);
+  if (variant == 3) return dispatch<2, 4, 1>(p, d->amode, d->epi, s);
   return dispatch<2, 4, 2>(p, d->amode, d->epi, s);
 }
 

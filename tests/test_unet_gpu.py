@@ -140,3 +140,23 @@ def test_stage2_refine_loop_matches_reference_golden(dev):
     rel, cos = stats(out, fx["output"])
     print(f"v02 loop: rel {rel:.4f} cos {cos:.6f}")
     assert rel < 6e-2 and cos > 0.999
+
+
+def test_unet_32_views_vs_oracle(dev):
+    """BASELINE config 4 shape family: T = 32 views (temporal attention over 32 frames, 3-D
+    GroupNorm / Conv3d over 32 frames), reduced width and latent so the oracle runs in seconds."""
+    from oracle import hi3d_oracle as O
+    fx = load("unet_tiny_s2_ioi")
+    cfg, T, H, W = fx["cfg"], 32, 8, 8
+    m = build_unet(fx, dev)
+    sd = {fx["key_prefix"] + k: v.float().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((2 * T, cfg["in_channels"], H, W), generator=g)
+    ts = 0.25 * torch.log(torch.rand((2 * T,), generator=g) * 100 + 0.01)
+    ctx, y = torch.randn((2, 1, 1024), generator=g), torch.randn((2, cfg["adm_in_channels"]), generator=g)
+    ioi = torch.zeros(2, T)
+    ref = O.video_unet(sd, cfg, x, ts, ctx, y, T, ioi, prefix=fx["key_prefix"])
+    out = m(x.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T, image_only_indicator=ioi.to(dev))
+    rel, cos = stats(out, ref)
+    print(f"32 views: rel {rel:.4f} cos {cos:.6f}")
+    assert rel < 4e-2 and cos > 0.9995
