@@ -30,6 +30,8 @@ struct GemmParams {
 };
 
 constexpr int BK = 64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // WM   : waves along M (2 -> 128-row tile, 4 waves; 4 -> 256-row tile, 8 waves); 2 waves along N
 // NT   : 16-column MFMA tiles per wave along N (4 -> BN = 128, 5 -> BN = 160)
@@ -37,7 +39,7 @@ constexpr int BK = 64;
 //        NS = 3: two K-steps in flight, counted vmcnt (the newest stage's LDS-DMA stays in
 //        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
 template <int WM, int NT, int NS, int AMODE, int EPI>
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
   constexpr int BM = WM * 64, BN = 32 * NT;
@@ -188,7 +190,71 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   // lane (fg, fr) owns rows m = m0 + wm*64 + mt*16 + fr, columns nb .. nb + 4*NT - 1
   const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
 
+  constexpr int BN_OUT = (EPI == HI3D_EPI_GEGLU) ? BN / 2 : BN;
+  constexpr int LROW = BN_OUT * 4 + 16;            // bytes; +16 spreads ds_write_b128 lanes over banks
+  constexpr int MPP = (NS == 1) ? 1 : 2;           // 16-row accumulator blocks per wave and pass
+  constexpr int NPASS = 4 / MPP;
+  constexpr int HR = WM * 16 * MPP;                // rows per pass (fits the ring: checked below)
+  static_assert(HR * LROW <= NS * STAGE, "epilogue slab does not fit the LDS ring");
+  constexpr int CPR = BN_OUT / 8;                  // 8-column chunks per row
+  constexpr int NTHR = NW * 64;
+  const int n0_out = (EPI == HI3D_EPI_GEGLU) ? n0 / 2 : n0;
+  const int N_out = (EPI == HI3D_EPI_GEGLU) ? p.N / 2 : p.N;
+  constexpr int CH = (HR * CPR + NTHR - 1) / NTHR;  // 8-column chunks per thread and pass
+
+  // ---- epilogue operands that do not depend on the accumulators are fetched early, not in the
+  // epilogue: a global load issued there queues behind the other resident block's LDS-DMA stream
+  // and costs 4-12 K cycles (measured with s_memtime stamps) -- as much as a short K loop.
+  // Bias and (when every row of the tile is in one group) the group's row vector and blend
+  // factors are fetched before the K loop; the R1 tile is requested two K steps before the
+  // loop ends, R2 one pass ahead of its use, both in the row-contiguous 16 B/lane layout of
+  // the store pass, through buffer descriptors (out-of-range -> zeros).
+  const bool ugrp = p.rpg > 0 && (p.rpg % BM) == 0;
+  const int tgrp = ugrp ? m0 / p.rpg : 0;
+  // bias[n0 ..] and rowvec[tgrp][n0 ..] land in two 1 KiB LDS slots behind the ring (one LDS-DMA
+  // each, wave 0; a zero-length descriptor zero-fills the slot of an absent vector)
+  char* const vec_lds = smem + NS * STAGE;
+  if (w == 0) {
+    const int nrem = (p.N - n0) * 4;
+    const bool rvt = EPI == HI3D_EPI_AFFINE && p.rowvec && ugrp;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        p.bias ? (void*)(p.bias + n0) : (void*)p.W, 0, p.bias ? nrem : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        rvt ? (void*)(p.rowvec + (long)tgrp * p.ldrv + n0) : (void*)p.W, 0, rvt ? nrem : 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)vec_lds, 16, lane * 16, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(vec_lds + 1024), 16, lane * 16, 0, 0, 0);
+  }
+  float ts1 = 1.0f, ts2 = 1.0f;
+  if (EPI == HI3D_EPI_AFFINE && ugrp) { if (p.a1) ts1 = p.a1[tgrp]; if (p.a2) ts2 = p.a2[tgrp]; }
+
+  // chunk c = tid + i*NTHR of a pass covers LDS row lr = c / CPR, columns 8*(c % CPR) .. +7;
+  // its tile row is trow(lr) + pass * 16*MPP.
+  auto chunk_row = [&](int i) { const int lr = (tid + i * NTHR) / CPR; return (lr / (16 * MPP)) * 64 + (lr % (16 * MPP)); };
+  auto chunk_col = [&](int i) { return ((tid + i * NTHR) % CPR) * 8; };
+  auto chunk_ok = [&](int i, int pass) {
+    return tid + i * NTHR < HR * CPR && n0_out + chunk_col(i) < N_out && m0 + chunk_row(i) + pass * 16 * MPP < p.M;
+  };
+  u32x4 r1v[NPASS][CH], r2v[CH];
+  auto fetch_residual = [&](const unsigned short* R, int ldr, int pass, u32x4 (&dst)[CH]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(R + (long)m0 * ldr + n0_out), 0, 0x7fffffff, 0x00020000);
+    const int so = pass * 16 * MPP * ldr * 2;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int col = chunk_col(i);
+      const bool has8 = n0_out + col + 8 <= N_out;
+      const unsigned vo = chunk_ok(i, pass) ? (unsigned)((chunk_row(i) * ldr + col) * 2) : INV;
+      if (has8 && p.vec8) {
+        dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+      } else {                                      // 8-byte pieces: narrow or unaligned rows
+        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, has8 ? vo + 8 : INV, so, 0);
+        dst[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+    }
+  };
+
   const int nk = p.K / BK;
+  const int pf_kt = nk >= 2 ? nk - 2 : 0;
   if (NS != 1) issue(0, 0);
   if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;
@@ -209,6 +275,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                        // stage st landed; stage st^1 free again
       if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+    }
+    if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < 64) {   // both vector slots have landed: fold them
+      f32x4 b = *(const f32x4*)(vec_lds + tid * 16);            // (read again only after later barriers)
+      const f32x4 g = *(const f32x4*)(vec_lds + 1024 + tid * 16);
+      b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
+      *(f32x4*)(vec_lds + tid * 16) = b;
+    }
+    if (EPI == HI3D_EPI_AFFINE && p.R1 && kt == pf_kt) {
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
     }
     const char* s = smem + st * STAGE;
 #pragma unroll
@@ -233,18 +309,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
   // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
   // directly that is 64 scattered 8-byte requests per instruction, and the L2 request rate --
   // not bandwidth -- bounds every short-K GEMM.  So the fp32 tile goes through LDS (the
-  // ring is free now), two half-tiles of BM/2 rows, and all global traffic (residual loads,
+  // ring is free now), NPASS slabs of HR rows, and all global traffic (residual loads,
   // stores) is issued row-contiguous, 16 bytes per lane.
-  constexpr int BN_OUT = (EPI == HI3D_EPI_GEGLU) ? BN / 2 : BN;
-  constexpr int LROW = BN_OUT * 4 + 16;            // bytes; +16 spreads ds_write_b128 lanes over banks
-  constexpr int MPP = (NS == 1) ? 1 : 2;           // 16-row accumulator blocks per wave and pass
-  constexpr int NPASS = 4 / MPP;
-  constexpr int HR = WM * 16 * MPP;                // rows per pass (fits the ring: checked below)
-  static_assert(HR * LROW <= NS * STAGE, "epilogue slab does not fit the LDS ring");
-  constexpr int CPR = BN_OUT / 8;                  // 8-column chunks per row
-  constexpr int NTHR = NW * 64;
-  const int n0_out = (EPI == HI3D_EPI_GEGLU) ? n0 / 2 : n0;
-  const int N_out = (EPI == HI3D_EPI_GEGLU) ? p.N / 2 : p.N;
+  if (EPI == HI3D_EPI_AFFINE && p.R2) fetch_residual(p.R2, p.ldr2, 0, r2v);
+  const int osz = p.out_fp32 ? 4 : 2;
+  const __amdgpu_buffer_rsrc_t rsO =
+      __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
   __syncthreads();                                 // every wave is done with the operand ring
 #pragma unroll
   for (int half = 0; half < NPASS; ++half) {
@@ -255,13 +325,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cl = wn * 16 * NT + fg * 4 * NT + nt * 4;    // tile-local column of acc[mt][nt][0]
-        const int n = n0 + cl;
         f32x4 v = acc[mt][nt];
         if (EPI == HI3D_EPI_GEGLU) {
-          if (p.bias && n < p.N) {
-            const f32x4 b = *(const f32x4*)(p.bias + n);
-            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-          }
+          const f32x4 b = *(const f32x4*)(vec_lds + cl * 4);
+          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
           const hi3d_f2 gl = gelu_erf_f2(hi3d_f2{v[2], v[3]});
           float2 o; o.x = v[0] * gl[0]; o.y = v[1] * gl[1];
           *(float2*)(trow + (cl >> 1) * 4) = o;
@@ -271,61 +338,62 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
       }
     }
     __syncthreads();
-    for (int c = tid; c < HR * CPR; c += NTHR) {
-      const int lr = c / CPR, c8 = c - lr * CPR;
-      const int m = m0 + (lr / (16 * MPP)) * 64 + half * 16 * MPP + (lr % (16 * MPP));
-      const int n = n0_out + c8 * 8;
-      if (m >= p.M || n >= N_out) continue;
-      const char* tp = smem + lr * LROW + c8 * 32;
-      const f32x4 lo = *(const f32x4*)tp, hi = *(const f32x4*)(tp + 16);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int lr = (tid + i * NTHR) / CPR, col = chunk_col(i);
+      const bool ok = chunk_ok(i, half);
+      const int n = n0_out + col;
+      const bool has8 = n + 8 <= N_out;
+      const char* tp = smem + lr * LROW + col * 4;
+      f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+      if (tid + i * NTHR < HR * CPR) { lo = *(const f32x4*)tp; hi = *(const f32x4*)(tp + 16); }
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const bool full = (n + 8 <= N_out) && p.vec8;          // else: only the first 4 columns exist / are aligned
       if (EPI == HI3D_EPI_AFFINE) {
-        const int grp = (p.rowvec || p.a1 || p.a2) ? m / p.rpg : 0;
-        if (p.bias) {
-          const f32x4 b0 = *(const f32x4*)(p.bias + n);
-          v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
-          if (n + 8 <= N_out) { const f32x4 b1 = *(const f32x4*)(p.bias + n + 4); v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3]; }
+        {                                            // bias + the tile's row vector (zeros when absent)
+          const f32x4 b0 = *(const f32x4*)(vec_lds + col * 4), b1 = *(const f32x4*)(vec_lds + col * 4 + 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
         }
-        if (p.rowvec) {
+        const int m = m0 + chunk_row(i) + half * 16 * MPP;
+        const int grp = (ok && !ugrp && (p.rowvec || p.a1 || p.a2)) ? m / p.rpg : 0;
+        if (p.rowvec && !ugrp && ok) {               // tile spans groups (tiny grids only)
           const float* rv = p.rowvec + (long)grp * p.ldrv + n;
           const f32x4 r0 = *(const f32x4*)rv;
           v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
-          if (n + 8 <= N_out) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
+          if (has8) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
         }
         if (p.R1) {
-          const unsigned short* rp = p.R1 + (long)m * p.ldr1 + n;
-          uint4 r;
-          if (full) r = *(const uint4*)rp; else { const uint2 t = *(const uint2*)rp; r = make_uint4(t.x, t.y, 0, 0); if (n + 8 <= N_out) { const uint2 u = *(const uint2*)(rp + 4); r.z = u.x; r.w = u.y; } }
-          v[0] += bf16_to_f32(r.x & 0xffff); v[1] += bf16_to_f32(r.x >> 16); v[2] += bf16_to_f32(r.y & 0xffff); v[3] += bf16_to_f32(r.y >> 16);
-          v[4] += bf16_to_f32(r.z & 0xffff); v[5] += bf16_to_f32(r.z >> 16); v[6] += bf16_to_f32(r.w & 0xffff); v[7] += bf16_to_f32(r.w >> 16);
+          const u32x4 r = r1v[half][i];
+          v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
+          v[4] += bf16_to_f32(r[2] & 0xffff); v[5] += bf16_to_f32(r[2] >> 16); v[6] += bf16_to_f32(r[3] & 0xffff); v[7] += bf16_to_f32(r[3] >> 16);
         }
-        if (p.a1) { const float s1 = p.a1[grp];
+        if (p.a1) { const float s1 = ugrp ? ts1 : p.a1[grp];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= s1; }
         if (p.R2) {
-          const float s2 = p.a2 ? p.a2[grp] : 1.0f;
-          const unsigned short* rp = p.R2 + (long)m * p.ldr2 + n;
-          uint4 r;
-          if (full) r = *(const uint4*)rp; else { const uint2 t = *(const uint2*)rp; r = make_uint4(t.x, t.y, 0, 0); if (n + 8 <= N_out) { const uint2 u = *(const uint2*)(rp + 4); r.z = u.x; r.w = u.y; } }
-          v[0] += s2 * bf16_to_f32(r.x & 0xffff); v[1] += s2 * bf16_to_f32(r.x >> 16); v[2] += s2 * bf16_to_f32(r.y & 0xffff); v[3] += s2 * bf16_to_f32(r.y >> 16);
-          v[4] += s2 * bf16_to_f32(r.z & 0xffff); v[5] += s2 * bf16_to_f32(r.z >> 16); v[6] += s2 * bf16_to_f32(r.w & 0xffff); v[7] += s2 * bf16_to_f32(r.w >> 16);
+          const float s2 = ugrp ? ts2 : (p.a2 ? p.a2[grp] : 1.0f);
+          const u32x4 r = r2v[i];
+          v[0] += s2 * bf16_to_f32(r[0] & 0xffff); v[1] += s2 * bf16_to_f32(r[0] >> 16); v[2] += s2 * bf16_to_f32(r[1] & 0xffff); v[3] += s2 * bf16_to_f32(r[1] >> 16);
+          v[4] += s2 * bf16_to_f32(r[2] & 0xffff); v[5] += s2 * bf16_to_f32(r[2] >> 16); v[6] += s2 * bf16_to_f32(r[3] & 0xffff); v[7] += s2 * bf16_to_f32(r[3] >> 16);
         }
       }
+      // stores through the descriptor: out-of-range chunks carry the INV offset and are dropped
+      const unsigned vo = ok ? (unsigned)((chunk_row(i) * p.ldo + col) * osz) : INV;
+      const int so = half * 16 * MPP * p.ldo * osz;
       if (p.out_fp32) {
-        float* op = (float*)p.out + (long)m * p.ldo + n;
-        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
-        if (n + 8 <= N_out) *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsO, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsO, has8 ? vo + 16 : INV, so, 0);
       } else {
-        unsigned short* op = (unsigned short*)p.out + (long)m * p.ldo + n;
-        if (full) {
-          *(uint4*)op = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        const u32x4 pk = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        if (has8 && p.vec8) {
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rsO, vo, so, 0);
         } else {
-          *(uint2*)op = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          if (n + 8 <= N_out) *(uint2*)(op + 4) = make_uint2(pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rsO, vo, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[2], pk[3]}, rsO, has8 ? vo + 8 : INV, so, 0);
         }
       }
     }
+    if (EPI == HI3D_EPI_AFFINE && p.R2 && half + 1 < NPASS) fetch_residual(p.R2, p.ldr2, half + 1, r2v);
     if (half + 1 < NPASS) __syncthreads();
   }
 #endif
@@ -333,7 +401,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 
 template <int WM, int NT, int NS, int AMODE, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
-  constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2);
+  constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2048;   // ring + bias / row-vector slots
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>,
@@ -437,7 +505,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
 extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
   int n = -1;
 #define OCC(WM, NT, NS) if (wm == WM && nt == NT && ns == NS) { \
-    constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2); \
+    constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2048; \
     hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, WM * 128, smem); }
   OCC(2, 5, 2) OCC(2, 4, 2) OCC(4, 5, 3) OCC(4, 4, 3) OCC(2, 5, 3) OCC(2, 4, 3)
