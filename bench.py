@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +167,12 @@ def main():
             log(f"[bench] {fam:16s} {d['ms'] / a.steps:9.3f} ms/step  {d['launches'] // a.steps:4d} launches/step  "
                 f"{tf:8.1f} TFLOP/s  {gbs:8.1f} GB/s(alg)")
         log(f"[bench] kernels total {total_ms / a.steps:.2f} ms/step of {ms_per_step:.2f} ms/step wall")
+        if a.shapes:
+            for fam, d in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:40]:
+                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                log(f"[bench]   {fam:60s} {d['ms'] / a.steps:8.3f} ms/step {d['launches'] // a.steps:4d}x "
+                    f"{d['ms'] / d['launches']:7.3f} ms each {tf:7.1f} TFLOP/s {gbs:7.0f} GB/s(alg)")
         # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
         g = [d for f, d in summ.items() if f.startswith("gemm_")]
         g_ms, g_fl, g_n = sum(d["ms"] for d in g), sum(d["flops"] for d in g), sum(d["launches"] for d in g)

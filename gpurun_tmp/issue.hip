@@ -1,0 +1,109 @@
+// Issue-rate probe: v_exp_f32, v_pk_fma_f32, MFMA 32x32x16, and their overlap within / across waves.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f2;
+#define N 4096
+template <int ROLE> __device__ __forceinline__ float run(float seed) {
+  if (ROLE == 0) {          // 8 independent exp
+    float e[8]; for (int i = 0; i < 8; ++i) e[i] = seed * (i + 1);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+    float s = 0; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  } else if (ROLE == 1) {   // 8 independent fma
+    float e[8]; for (int i = 0; i < 8; ++i) e[i] = seed * (i + 1);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = __builtin_fmaf(e[i], 1.0001f, 0.5f);
+    float s = 0; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  } else if (ROLE == 2) {   // 4 independent MFMA 32x32x16
+    f32x16 acc[4]; for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    bf16x8 a = (bf16x8)(short)(seed), b = (bf16x8)(short)(seed * 2);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][5]; return s;
+  } else if (ROLE == 3) {   // one wave: 4 MFMA + 8 exp interleaved
+    f32x16 acc[4]; for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    bf16x8 a = (bf16x8)(short)(seed), b = (bf16x8)(short)(seed * 2);
+    float e[8]; for (int i = 0; i < 8; ++i) e[i] = seed * (i + 1);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        e[2 * i] = __builtin_amdgcn_exp2f(e[2 * i]); e[2 * i + 1] = __builtin_amdgcn_exp2f(e[2 * i + 1]);
+      }
+    float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][5]; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  } else if (ROLE == 4) {   // 8 independent pk_fma
+    f2 pf[8]; for (int i = 0; i < 8; ++i) pf[i] = f2{seed * i, seed};
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pf[i] = pf[i] * f2{1.0001f, 1.0002f} + f2{0.5f, 0.25f};
+    float s = 0; for (int i = 0; i < 8; ++i) s += pf[i][0] + pf[i][1]; return s;
+  } else if (ROLE == 5) {   // one wave: 4 MFMA + 24 fma interleaved
+    f32x16 acc[4]; for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    bf16x8 a = (bf16x8)(short)(seed), b = (bf16x8)(short)(seed * 2);
+    float e[8]; for (int i = 0; i < 8; ++i) e[i] = seed * (i + 1);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) e[(i * 2 + j) & 7] = __builtin_fmaf(e[(i * 2 + j) & 7], 1.0001f, 0.5f);
+      }
+    float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][5]; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  } else if (ROLE == 6) {   // 8 independent MFMA 16x16x32
+    f32x4 acc[8]; for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    bf16x8 a = (bf16x8)(short)(seed), b = (bf16x8)(short)(seed * 2);
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    float s = 0; for (int i = 0; i < 8; ++i) s += acc[i][0]; return s;
+  } else if (ROLE == 7) {   // 8 cvt_pk
+    float e[8]; for (int i = 0; i < 8; ++i) e[i] = seed * (i + 1);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    for (int it = 0; it < N; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bf2 r = __builtin_convertvector(f2{e[i], e[(i + 1) & 7]}, bf2); e[i] += (float)r[0]; }
+    float s = 0; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  }
+  return 0;
+}
+template <int RA, int RB>
+__global__ __launch_bounds__(512) void k(float seed, float* out) {
+  const int w = threadIdx.x >> 6;
+  float s;
+  if (w < 4) s = run<RA>(seed); else { if (RB < 0) return; s = run<(RB < 0 ? 0 : RB)>(seed); }
+  if (s == 1234.5f) out[0] = s;
+}
+template <int RA, int RB> void go(const char* name, float* out) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k<RA, RB>), dim3(256), dim3(512), 0, 0, 0.5f, out);
+    hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+  }
+  printf("%-44s: %.3f ms -> %.1f cycles/iter @2.4GHz\n", name, ms, ms * 1e-3 * 2.4e9 / N);
+}
+int main() {
+  float* out; hipMalloc(&out, 4);
+  go<0, -1>("exp x8", out);
+  go<1, -1>("fma x8", out);
+  go<4, -1>("pk_fma x8", out);
+  go<7, -1>("cvt_pk+add x8", out);
+  go<2, -1>("mfma32 x4", out);
+  go<6, -1>("mfma16 x8", out);
+  go<3, -1>("one wave: mfma32 x4 + exp x8", out);
+  go<5, -1>("one wave: mfma32 x4 + fma x24", out);
+  go<2, 0>("wave A mfma32 x4 | wave B exp x8", out);
+  go<2, 1>("wave A mfma32 x4 | wave B fma x8", out);
+  go<2, 2>("wave A mfma32 x4 | wave B mfma32 x4", out);
+  go<0, 0>("wave A exp x8 | wave B exp x8", out);
+  go<1, 1>("wave A fma x8 | wave B fma x8", out);
+  go<3, 3>("both: mfma32 x4 + exp x8", out);
+  return 0;
+}

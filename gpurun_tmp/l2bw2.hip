@@ -1,0 +1,83 @@
+// L2 -> LDS streaming + MFMA overlap probe: GEMM main loop skeleton (NS=2 ring).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define LDS_AS __attribute__((address_space(3)))
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int MODE>   // bit0: MFMAs, bit1: ds_reads
+__global__ __launch_bounds__(256, 2) void stream(const char* base, long span, int steps, int pitch, float* sink) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS = 288, STAGE = ROWS * 128;
+  const char* origin = base + ((long)blockIdx.x * ROWS * pitch) % span;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int k, int st) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int q = w + 4 * i;
+      const unsigned vo = (unsigned)((q * 8 + (lane >> 3)) * pitch + (lane & 7) * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(smem + st * STAGE + q * 1024), 16, vo, k * 128, 0, 0);
+    }
+  };
+  f32x4 acc[4][5];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  bf16x8 xf[4], wf[5];
+  for (int i = 0; i < 4; ++i) xf[i] = (bf16x8)(short)(lane + i);
+  for (int i = 0; i < 5; ++i) wf[i] = (bf16x8)(short)(lane * 3 + i);
+  issue(0, 0);
+  int st = 0;
+  for (int k = 0; k < steps; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k + 1 < steps) issue(k + 1, st ^ 1);
+    const char* s = smem + st * STAGE;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      if (MODE & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(s + ((w >> 1) * 64 + i * 16 + (lane & 15)) * 128 + (((kh * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wf[i] = *(const bf16x8*)(s + 16384 + ((w & 1) * 80 + i * 16 + (lane & 15)) * 128 + (((kh * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4));
+      }
+      if (MODE & 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    st ^= 1;
+  }
+  float t = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (t == 12345.f) sink[0] = t + xf[0][0];
+#endif
+}
+template <int MODE> void run(char* buf, long span, int steps, int pitch, float* sink, int bpc) {
+  const int lds = 2 * 288 * 128;
+  hipFuncSetAttribute((const void*)stream<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int grid = 256 * bpc * 8;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float ms = 0;
+  for (int it = 0; it < 3; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(stream<MODE>, dim3(grid), dim3(256), lds, 0, buf, span, steps, pitch, sink);
+    hipEventRecord(b); hipEventSynchronize(b);
+    hipEventElapsedTime(&ms, a, b);
+  }
+  const double bytes = (double)grid * steps * 288 * 128, flops = (double)grid * steps * 2.0 * 128 * 160 * 64;
+  printf("mode %d span %6.1f MB steps %d pitch %d: %.3f ms  %.2f TB/s  %.0f TFLOP/s-equiv  (%.0f cycles/step/block @2.4GHz)\n", MODE, span / 1e6, steps, pitch, ms, bytes / ms / 1e9, flops / ms / 1e9,
+         ms * 1e-3 * 2.4e9 / (8.0 * steps) );
+}
+int main(int argc, char** argv) {
+  const long span = atol(argv[1]); const int steps = atoi(argv[2]), pitch = atoi(argv[3]);
+  char* buf; float* sink;
+  hipMalloc(&buf, span + (1l << 28)); hipMemset(buf, 0, span + (1l << 28)); hipMalloc(&sink, 4);
+  run<0>(buf, span, steps, pitch, sink, 2);
+  run<1>(buf, span, steps, pitch, sink, 2);
+  run<2>(buf, span, steps, pitch, sink, 2);
+  run<3>(buf, span, steps, pitch, sink, 2);
+  return 0;
+}

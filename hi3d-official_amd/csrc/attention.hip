@@ -35,8 +35,11 @@ struct AttnParams {
 };
 
 constexpr int KV_TILE = 64;
-constexpr float RESCALE_THR = 6.0f;   // log2 domain
+constexpr float SUM_MAX = 2048.0f;     // a key tile's 32-term row sum of P above this triggers the exact rescale
 constexpr int ATT_STAGE = 2 * KV_TILE * 128;   // K tile 8 KiB + V^T tile 8 KiB
+
+constexpr int QB = 2;                  // 32-row query blocks per wave
+constexpr int Q_TILE = 4 * QB * 32;    // query rows per block
 
 __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
@@ -57,14 +60,24 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 
   const char* zero = (const char*)hi3d_zero_page;
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[row li][d = ks*16 + hi*8 ..+7]
-  const int qrow = qt * 128 + w * 32 + li;
-  const bool qok = qrow < p.Sq;
-  bf16x8 qf[4];
-  {
-    const char* qp = p.q + (((long)b * p.Sq + (qok ? qrow : 0)) * p.ldq + h * 64) * 2;
+  // of each of the wave's QB query blocks, pre-multiplied by scale*log2(e) so that a score is
+  // an exp2 argument as it comes out of the MFMA.
+  int qrow[QB]; bool qok[QB];
+  bf16x8 qf[QB][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = qok ? *(const bf16x8*)(qp + (ks * 16 + hi * 8) * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int qb = 0; qb < QB; ++qb) {
+    qrow[qb] = qt * Q_TILE + (w * QB + qb) * 32 + li;
+    qok[qb] = qrow[qb] < p.Sq;
+    const char* qp = p.q + (((long)b * p.Sq + (qok[qb] ? qrow[qb] : 0)) * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { bf16x8 v; unsigned int u[4]; } raw, sq;
+      raw.v = qok[qb] ? *(const bf16x8*)(qp + (ks * 16 + hi * 8) * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        sq.u[t] = pack_bf16x2(bf16_to_f32(raw.u[t] & 0xffff) * p.scale_log2, bf16_to_f32(raw.u[t] >> 16) * p.scale_log2);
+      qf[qb][ks] = sq.v;
+    }
   }
 
   // ---- LDS-DMA gather state: K tile rows (keys) and V^T tile rows (d), 8 KiB each =
@@ -98,116 +111,184 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     }
   };
 
-  // fragment read offsets
-  const int k_sw = (li >> 1) & 7, v_sw = (li >> 1) & 7;
-  int k_off[2], vt_off[2];
+  // fragment read addresses: one LDS pointer per k-step (the XOR swizzle is lane-specific),
+  // moved between the ring stages once per tile; key block / d block are ds_read offsets
+  const int f_sw = (li >> 1) & 7;
+  const char* k_ptr[4]; const char* v_ptr[4];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) k_off[kb] = (kb * 32 + swap_bits23(li)) * 128;
-#pragma unroll
-  for (int db = 0; db < 2; ++db) vt_off[db] = KV_TILE * 128 + (db * 32 + li) * 128;
+  for (int ks = 0; ks < 4; ++ks) {
+    k_ptr[ks] = smem + swap_bits23(li) * 128 + (((ks * 2 + hi) ^ f_sw) << 4);
+    v_ptr[ks] = smem + KV_TILE * 128 + li * 128 + (((ks * 2 + hi) ^ f_sw) << 4);
+  }
+  int stage_step = ATT_STAGE;
 
-  f32x16 o[2];
+  f32x16 o[QB][2];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
+  // Softmax bookkeeping in the log2 domain of the pre-scaled scores.  The common path does not
+  // compute the tile maximum: P = exp2(S - m_run) is formed as each 32-key score block leaves
+  // the MFMA (which already subtracted m_run, see negm), and only the row sums (needed anyway) are checked at the end of the tile.  Softmax
+  // is invariant to the shift, so any m_run that keeps P bounded is as good as the true
+  // maximum.  When a row sum exceeds SUM_MAX (or is not finite), and on the first tile, the
+  // tile is redone by the exact path: scores recomputed, true maximum, O and l rescaled.
+  // Both branches are wave-uniform.
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = 0.f; l_run[qb] = 0.f; }
+  // -m_run in 16 equal registers per query block: the C operand of a tile's first score MFMA,
+  // so the subtraction costs no VALU instruction (rewritten only by the exact path)
+  f32x16 negm[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int ntile = (p.Skv + KV_TILE - 1) / KV_TILE;
   issue(0, 0);
   for (int j = 0; j < ntile; ++j) {
-    const int st = j & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (j + 1 < ntile) issue(j + 1, st ^ 1);
-    const char* s = smem + st * ATT_STAGE;
+    if (j + 1 < ntile) issue(j + 1, (j & 1) ^ 1);
+    const bool ragged = (j + 1) * KV_TILE > p.Skv;     // last tile with keys >= Skv to mask
 
-    // S^T = K Q^T  (two 32-key blocks)
-    f32x16 sc[2];
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16x8 pf[QB][4];
+    float psum[QB];
+    bool redo = (j == 0) || ragged;                    // masking lives in the exact path only
+    if (!redo) {
+      hi3d_f2 ps[QB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int qb = 0; qb < QB; ++qb) ps[qb] = hi3d_f2{0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(s + k_off[kb] + (((ks * 2 + hi) ^ k_sw) << 4));
-        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
+      for (int kb = 0; kb < 2; ++kb) {
+        // S^T = K Q^T for 32 keys x the wave's 64 query rows: every K fragment feeds QB MFMAs
+        f32x16 sc[QB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? negm[qb] : sc[qb], 0, 0, 0);
+        }
+        // lane registers: sc[qb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            union { bf16x8 v; unsigned int u[4]; } pk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              hi3d_f2 e;
+              e[0] = __builtin_amdgcn_exp2f(sc[qb][half * 8 + 2 * t]);
+              e[1] = __builtin_amdgcn_exp2f(sc[qb][half * 8 + 2 * t + 1]);
+              ps[qb] += e;
+              pk.u[t] = pack_bf16x2(e[0], e[1]);
+            }
+            pf[qb][kb * 2 + half] = pk.v;
+          }
+        }
+      }
+      bool ok = true;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) { psum[qb] = ps[qb][0] + ps[qb][1]; ok = ok && (psum[qb] <= SUM_MAX); }   // NaN / inf fail too
+      redo = !__all(ok);
+    }
+    if (redo) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        f32x16 sc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
+            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
+          }
+          if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
+              sc[kb][r] = (kv >= p.Skv) ? -INFINITY : sc[kb][r];
+            }
+          }
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // the row's other 32 keys of this tile
+        // finite: every tile has >= 1 valid key.  The reference point never moves down.
+        const float m_new = (j == 0) ? mx : fmaxf(m_run[qb], mx);
+        const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+        float acc = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            union { bf16x8 v; unsigned int u[4]; } pk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float e0 = __builtin_amdgcn_exp2f(sc[kb][half * 8 + 2 * t] - m_new);
+              const float e1 = __builtin_amdgcn_exp2f(sc[kb][half * 8 + 2 * t + 1] - m_new);
+              acc += e0 + e1;
+              pk.u[t] = pack_bf16x2(e0, e1);
+            }
+            pf[qb][kb * 2 + half] = pk.v;
+          }
+        psum[qb] = acc;
       }
     }
-    // lane registers: sc[kb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
-    if ((j + 1) * KV_TILE > p.Skv) {   // ragged last tile: mask keys >= Skv
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
-          sc[kb][r] = (kv >= p.Skv) ? -INFINITY : sc[kb][r];
-        }
-    }
-    float mx = sc[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // Deferred rescale: keep the old running max while the tile max exceeds it by at most
-    // 2^RESCALE_THR (P then stays <= 2^THR, harmless for bf16 P / fp32 accumulators); the
-    // branch is wave-uniform.  The very first tile always rescales (m_run = -inf).
-    const float m_tile = mx * p.scale_log2;                // finite: every tile has >= 1 valid key
-    float alpha = 1.0f;
-    if (!__all(m_tile - m_run <= RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, m_tile);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    const float m_new = m_run;
-    float psum = 0.f;
-    bf16x8 pf[4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float e[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          e[t] = __builtin_amdgcn_exp2f(sc[kb][half * 8 + t] * p.scale_log2 - m_new);
-          psum += e[t];
-        }
-        union { bf16x8 v; unsigned int u[4]; } pk;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pk.u[t] = pack_bf16x2(e[2 * t], e[2 * t + 1]);
-        pf[kb * 2 + half] = pk.v;
-      }
-    l_run = l_run * alpha + psum;
+    for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum[qb];
 
-    // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile)
+    // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile); every V^T
+    // fragment feeds QB MFMAs
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 vf = *(const bf16x8*)(s + vt_off[db] + (((ks * 2 + hi) ^ v_sw) << 4));
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
+        const bf16x8 vf = *(const bf16x8*)(v_ptr[ks] + db * 32 * 128);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], o[qb][db], 0, 0, 0);
       }
+    // flip the fragment pointers to the other ring stage
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { k_ptr[ks] += stage_step; v_ptr[ks] += stage_step; }
+    stage_step = -stage_step;
   }
 
   // ---- finish: both half-waves hold partial row sums of the same query row
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (qok) {
-    unsigned short* op = p.out + ((long)b * p.Sq + qrow) * p.ldo + h * 64;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qok[qb]) {
+      unsigned short* op = p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + h * 64;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // C rows (r&3) + 8*(r>>2) + 4*hi  ->  d = db*32 + g*8 + hi*4 + (0..3)
-        uint2 v;
-        v.x = pack_bf16x2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
-        v.y = pack_bf16x2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
-        *(uint2*)(op + db * 32 + g * 8 + hi * 4) = v;
-      }
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // C rows (r&3) + 8*(r>>2) + 4*hi  ->  d = db*32 + g*8 + hi*4 + (0..3)
+          uint2 v;
+          v.x = pack_bf16x2(o[qb][db][g * 4 + 0] * inv, o[qb][db][g * 4 + 1] * inv);
+          v.y = pack_bf16x2(o[qb][db][g * 4 + 2] * inv, o[qb][db][g * 4 + 3] * inv);
+          *(uint2*)(op + db * 32 + g * 8 + hi * 4) = v;
+        }
+    }
   }
 }
 
@@ -353,7 +434,7 @@ extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void*
   AttnParams p;
   p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)vt; p.out = (unsigned short*)out;
   p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_vt; p.ldo = ldo;
-  p.nqt = (S_q + 127) / 128;
+  p.nqt = (S_q + Q_TILE - 1) / Q_TILE;
   p.scale_log2 = scale * 1.4426950408889634f;
   const long nblk = (long)p.nqt * H * B;
   if (nblk > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: grid too large");

@@ -31,15 +31,18 @@ class Profiler:
         e.record()
         return e
 
-    def end(self, family, flops, nbytes, start):
+    def end(self, family, flops, nbytes, start, detail=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((family, float(flops), float(nbytes), start, e))
+        self.records.append((family, float(flops), float(nbytes), start, e, detail))
 
-    def summary(self):
-        """{family: dict(ms, launches, flops, bytes)} -- call after a device sync."""
+    def summary(self, by_shape=False):
+        """{family: dict(ms, launches, flops, bytes)} -- call after a device sync.
+        by_shape: key on the launch's shape string instead (where the op records one)."""
         out = {}
-        for fam, fl, nb, s, e in self.records:
+        for fam, fl, nb, s, e, detail in self.records:
+            if by_shape:
+                fam = f"{fam} {detail}" if detail else fam
             d = out.setdefault(fam, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d["ms"] += s.elapsed_time(e); d["launches"] += 1; d["flops"] += fl; d["bytes"] += nb
         return out
@@ -94,7 +97,11 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")
     if prof:
         fam = ("gemm_conv3x3" if conv3x3 is not None else "gemm_convt3" if convt3 is not None else "gemm_dense")
-        prof.end(fam, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), t0)
+        nres = (R1 is not None) + (R2 is not None)
+        epi = "geglu" if geglu else "+".join(x for x, on in (("b", bias is not None), ("rv", rowvec is not None),
+                                                            ("R1", R1 is not None), ("R2", R2 is not None)) if on)
+        prof.end(fam, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out * (1 + nres)), t0,
+                 detail=f"M={M} N={N} K={K} {epi}")
     return out
 
 
