@@ -483,7 +483,15 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU (default: fastest at every
   // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
   // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU.
+  // 3 = 128 rows, single stage, 3 blocks/CU.  Measured per shape (tools/kbench.py, MI355X):
+  // the GEGLU GEMMs (erf epilogue, VALU heavy) gain 9-15 % from the third resident block while
+  // K is short and 12 % from the 256-row tile at K >= 1280; plain GEMMs gain 3-7 % from the
+  // 256-row tile when both K and N are long; everything else, and every conv, is fastest at 0.
   int variant = 0;
+  if (d->amode == HI3D_A_DENSE) {
+    if (d->epi == HI3D_EPI_GEGLU) variant = d->K >= 1280 ? 2 : 3;
+    else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
+  }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
   const int bm = variant == 2 ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
