@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
   constexpr int BN_OUT = (EPI == HI3D_EPI_GEGLU) ? BN / 2 : BN;
   constexpr int LROW = BN_OUT * 4 + 16;            // bytes; +16 spreads ds_write_b128 lanes over banks
-  constexpr int MPP = (NS == 1) ? 1 : 2;           // 16-row accumulator blocks per wave and pass
+  constexpr int MPP = (NS == 1 || NT > 5) ? 1 : 2; // 16-row accumulator blocks per wave and pass
   constexpr int NPASS = 4 / MPP;
   constexpr int HR = WM * 16 * MPP;                // rows per pass (fits the ring: checked below)
   static_assert(HR * LROW <= NS * STAGE, "epilogue slab does not fit the LDS ring");
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // the store pass, through buffer descriptors (out-of-range -> zeros).
   const bool ugrp = p.rpg > 0 && (p.rpg % BM) == 0;
   const int tgrp = ugrp ? m0 / p.rpg : 0;
-  // bias[n0 ..] and rowvec[tgrp][n0 ..] land in two 1 KiB LDS slots behind the ring (one LDS-DMA
-  // each, wave 0; a zero-length descriptor zero-fills the slot of an absent vector)
+  // bias[n0 ..] and rowvec[tgrp][n0 ..] land in two LDS slots behind the ring (LDS-DMA by
+  // wave 0; a zero-length descriptor zero-fills the slot of an absent vector)
+  constexpr int VSLOT = (BN * 4 + 1023) / 1024 * 1024;   // bytes per vector slot (1 KiB per DMA)
   char* const vec_lds = smem + NS * STAGE;
   if (w == 0) {
     const int nrem = (p.N - n0) * 4;
@@ -221,8 +222,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         p.bias ? (void*)(p.bias + n0) : (void*)p.W, 0, p.bias ? nrem : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
         rvt ? (void*)(p.rowvec + (long)tgrp * p.ldrv + n0) : (void*)p.W, 0, rvt ? nrem : 0, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)vec_lds, 16, lane * 16, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(vec_lds + 1024), 16, lane * 16, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < VSLOT / 1024; ++c) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(vec_lds + c * 1024), 16, lane * 16 + c * 1024, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(vec_lds + VSLOT + c * 1024), 16, lane * 16 + c * 1024, 0, 0, 0);
+    }
   }
   float ts1 = 1.0f, ts2 = 1.0f;
   if (EPI == HI3D_EPI_AFFINE && ugrp) { if (p.a1) ts1 = p.a1[tgrp]; if (p.a2) ts2 = p.a2[tgrp]; }
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   auto chunk_ok = [&](int i, int pass) {
     return tid + i * NTHR < HR * CPR && n0_out + chunk_col(i) < N_out && m0 + chunk_row(i) + pass * 16 * MPP < p.M;
   };
-  u32x4 r1v[NPASS][CH], r2v[CH];
+  constexpr int RP = (NT > 5) ? 1 : NPASS;          // R1 passes held in registers at a time
+  u32x4 r1v[RP][CH], r2v[CH];
   auto fetch_residual = [&](const unsigned short* R, int ldr, int pass, u32x4 (&dst)[CH]) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(R + (long)m0 * ldr + n0_out), 0, 0x7fffffff, 0x00020000);
     const int so = pass * 16 * MPP * ldr * 2;
@@ -276,31 +281,36 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       __syncthreads();                        // stage st landed; stage st^1 free again
       if (kt + 1 < nk) issue(kt + 1, st ^ 1);
     }
-    if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < 64) {   // both vector slots have landed: fold them
+    if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < VSLOT / 16) {   // both vector slots have landed: fold them
       f32x4 b = *(const f32x4*)(vec_lds + tid * 16);            // (read again only after later barriers)
-      const f32x4 g = *(const f32x4*)(vec_lds + 1024 + tid * 16);
+      const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
       b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
       *(f32x4*)(vec_lds + tid * 16) = b;
     }
-    if (EPI == HI3D_EPI_AFFINE && p.R1 && kt == pf_kt) {
+    if (EPI == HI3D_EPI_AFFINE && NT <= 5 && p.R1 && kt == pf_kt) {
 #pragma unroll
-      for (int pass = 0; pass < NPASS; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
+      for (int pass = 0; pass < RP; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
     }
     const char* s = smem + st * STAGE;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      bf16x8 xf[4], wf[NT];
+      constexpr int NTH = (NT > 5) ? NT / 2 : NT;   // weight fragments held at a time
+      bf16x8 xf[4];
       const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
       const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nt] + cw);
+      for (int nh = 0; nh < NT / NTH; ++nh) {
+        bf16x8 wf[NTH];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int nt = 0; nt < NTH; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nh * NTH + nt] + cw);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTH; ++nt)
+            acc[mt][nh * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nh * NTH + nt], 0, 0, 0);
+      }
     }
     if (NS == 3) st = (st == 2) ? 0 : st + 1;
     else if (NS == 2) st ^= 1;
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // ring is free now), NPASS slabs of HR rows, and all global traffic (residual loads,
   // stores) is issued row-contiguous, 16 bytes per lane.
   if (EPI == HI3D_EPI_AFFINE && p.R2) fetch_residual(p.R2, p.ldr2, 0, r2v);
+  if (EPI == HI3D_EPI_AFFINE && NT > 5 && p.R1) fetch_residual(p.R1, p.ldr1, 0, r1v[0]);   // 160 accumulator registers: no room earlier
   const int osz = p.out_fp32 ? 4 : 2;
   const __amdgpu_buffer_rsrc_t rsO =
       __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           if (has8) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
         }
         if (p.R1) {
-          const u32x4 r = r1v[half][i];
+          const u32x4 r = r1v[half % RP][i];
           v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
           v[4] += bf16_to_f32(r[2] & 0xffff); v[5] += bf16_to_f32(r[2] >> 16); v[6] += bf16_to_f32(r[3] & 0xffff); v[7] += bf16_to_f32(r[3] >> 16);
         }
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       }
     }
     if (EPI == HI3D_EPI_AFFINE && p.R2 && half + 1 < NPASS) fetch_residual(p.R2, p.ldr2, half + 1, r2v);
+    if (EPI == HI3D_EPI_AFFINE && p.R1 && half + RP < NPASS) fetch_residual(p.R1, p.ldr1, half + RP, r1v[half % RP]);
     if (half + 1 < NPASS) __syncthreads();
   }
 #endif
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
 template <int WM, int NT, int NS, int AMODE, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
-  constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2048;   // ring + bias / row-vector slots
+  constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2 * ((32 * NT * 4 + 1023) / 1024 * 1024);   // ring + bias / row-vector slots
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>,
@@ -482,21 +494,25 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (tile != 128 && tile != 160) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 128 or 160");
   // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU (default: fastest at every
   // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
-  // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU.
+  // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU;
+  // 5 = 256 x 320 tile, 8 waves of 64 x 160 (half the L2->LDS bytes per FLOP), 1 block/CU.
   // 3 = 128 rows, single stage, 3 blocks/CU.  Measured per shape (tools/kbench.py, MI355X):
   // the GEGLU GEMMs (erf epilogue, VALU heavy) gain 9-15 % from the third resident block while
-  // K is short and 12 % from the 256-row tile at K >= 1280; plain GEMMs gain 3-7 % from the
-  // 256-row tile when both K and N are long; everything else, and every conv, is fastest at 0.
+  // K is short, and 12-16 % from the 256 x 320 tile (variant 5) at K >= 640; plain GEMMs gain
+  // 3-7 % from the 256-row tile when both K and N are long; everything else, and every conv,
+  // is fastest at 0.
   int variant = 0;
   if (d->amode == HI3D_A_DENSE) {
-    if (d->epi == HI3D_EPI_GEGLU) variant = d->K >= 1280 ? 2 : 3;
+    if (d->epi == HI3D_EPI_GEGLU) variant = (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
   }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
-  const int bm = variant == 2 ? 256 : 128;
+  if (variant == 5) tile = 320;             // 256 x 320 tile: 8 waves of 64 x 160, one block per CU
+  const int bm = (variant == 2 || variant == 5) ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
   hipStream_t s = (hipStream_t)stream;
+  if (tile == 320) return dispatch<4, 10, 2>(p, d->amode, d->epi, s);
   if (tile == 160) {
     if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
     if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);
@@ -513,7 +529,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
 extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
   int n = -1;
 #define OCC(WM, NT, NS) if (wm == WM && nt == NT && ns == NS) { \
-    constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2048; \
+    constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2 * ((32 * NT * 4 + 1023) / 1024 * 1024); \
     hipFuncSetAttribute((const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_bf16_kernel<WM, NT, NS, 0, 0>, WM * 128, smem); }
   OCC(2, 5, 2) OCC(2, 4, 2) OCC(4, 5, 3) OCC(4, 4, 3) OCC(2, 5, 3) OCC(2, 4, 3)
