@@ -14,8 +14,15 @@
 
 namespace {
 
-constexpr int GN_PPB = 512;        // pixels per stats block
-constexpr int GN_APPLY_PPB = 256;  // pixels per apply block
+constexpr int GN_PPB_MAX = 512;    // pixels per stats block: halved (down to GN_PPB_MIN) until the grid
+constexpr int GN_PPB_MIN = 64;     // has >= GN_MIN_BLOCKS blocks -- few, long blocks leave HBM idle
+constexpr int GN_MIN_BLOCKS = 1024;
+inline int gn_ppb(int inst, int P) {
+  int ppb = GN_PPB_MAX;
+  while (ppb > GN_PPB_MIN && (long)((P + ppb - 1) / ppb) * inst < GN_MIN_BLOCKS) ppb >>= 1;
+  return ppb;
+}
+constexpr int GN_APPLY_PPB = 256;  // pixels per apply block (fewer on small grids, like the stats blocks)
 
 __host__ __device__ inline int gn_threads(int C) {
   const int vec = C / 8;                       // 16-byte vectors per pixel
@@ -24,25 +31,26 @@ __host__ __device__ inline int gn_threads(int C) {
 }
 
 __global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial,
-                                int P, int C, int nblk) {
+                                int P, int C, int nblk, int ppb) {
   __shared__ float gs[64];
   const int vec = C >> 3, cpg = C >> 5;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
   const int inst = blockIdx.y, blk = blockIdx.x;
-  const int p_begin = blk * GN_PPB, p_end = min(P, p_begin + GN_PPB);
+  const int p_begin = blk * ppb, p_end = min(P, p_begin + ppb);
   const uint4* base = x + (long)inst * P * vec;
   float s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-  // 4 independent 16-byte loads in flight per thread (HBM latency hiding)
+  // 8 independent 16-byte loads in flight per thread (HBM latency hiding)
+  constexpr int UNR = 8;
   int p = p_begin + rsub;
-  for (; p + 3 * rows_per_sweep < p_end; p += 4 * rows_per_sweep) {
-    uint4 v[4];
+  for (; p + (UNR - 1) * rows_per_sweep < p_end; p += UNR * rows_per_sweep) {
+    uint4 v[UNR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = base[(long)(p + u * rows_per_sweep) * vec + chunk];
+    for (int u = 0; u < UNR; ++u) v[u] = base[(long)(p + u * rows_per_sweep) * vec + chunk];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const unsigned int w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_finalize_kernel(const fl
 template <bool SILU>
 __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ stats, int P, int C) {
+                                const float* __restrict__ stats, int P, int C, int appb) {
   const int vec = C >> 3, cpg = C >> 5;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
@@ -125,7 +133,7 @@ __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
     a[j] = rstd * gamma[c];
     b[j] = beta[c] - mean * a[j];
   }
-  const int p_begin = blockIdx.x * GN_APPLY_PPB, p_end = min(P, p_begin + GN_APPLY_PPB);
+  const int p_begin = blockIdx.x * appb, p_end = min(P, p_begin + appb);
   const long base = (long)inst * P * vec;
   auto norm8 = [&](const uint4 v) {
     const unsigned int u[4] = {v.x, v.y, v.z, v.w};
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 
 extern "C" int32_t hi3d_gn_partial_blocks(int32_t P, int32_t C) {
   (void)C;
-  return (P + GN_PPB - 1) / GN_PPB;
+  return (P + GN_PPB_MIN - 1) / GN_PPB_MIN;   // upper bound over the block sizes the launcher may pick
 }
 
 extern "C" int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C) {
@@ -241,20 +249,22 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
   if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int nblk = hi3d_gn_partial_blocks(P, C);
+  const int ppb = gn_ppb(inst, P);
+  const int nblk = (P + ppb - 1) / ppb;
   float* partial = ws;
-  float* stats = ws + (long)inst * nblk * 64;
+  float* stats = ws + (long)inst * hi3d_gn_partial_blocks(P, C) * 64;
   const int nthr = gn_threads(C);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, partial, P, C, nblk);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, partial, P, C, nblk, ppb);
   HI3D_LAUNCH_CHECK();
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, partial, stats, nblk, inv_count, eps);
   HI3D_LAUNCH_CHECK();
-  const int ablk = (P + GN_APPLY_PPB - 1) / GN_APPLY_PPB;
+  const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
+  const int ablk = (P + appb - 1) / appb;
   if (apply_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

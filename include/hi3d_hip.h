@@ -147,7 +147,9 @@ int hi3d_attn_temporal_d64(const void* q, const void* k, const void* v, void* ou
  * with inst = frames, P = H*W; the 3-D time_stack (video_model.py:71-76) with
  * inst = b, P = T*H*W -- same memory, no permute.
  *   ws : caller workspace of hi3d_gn_workspace_floats(inst, P, C) floats (partial
- *        sums + per-instance mean/rstd); contents are scratch.               */
+ *        sums + per-instance mean/rstd); contents are scratch.
+ * hi3d_gn_partial_blocks: upper bound of partial-sum blocks per instance (the
+ * launcher sizes its blocks to the grid it needs).                          */
 int32_t hi3d_gn_partial_blocks(int32_t P, int32_t C);
 int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C);
 int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,

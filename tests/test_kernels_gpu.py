@@ -72,6 +72,40 @@ def test_gemm_geglu(dev, M, Nh, K):
     assert relerr(out, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 5])
+def test_gemm_tile_variants(dev, variant, monkeypatch):
+    """The tile variants the host heuristic picks only for large shapes (256-row tiles, single-stage
+    ring, 256 x 320 tile) forced onto small ragged shapes: every epilogue, conv gather and GEGLU."""
+    from hi3d_hip import ops
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
+    M, N, K, rpg = 700, 640, 320, 256            # rpg multiple of the 256-row tile and not (M tail)
+    G = (M + rpg - 1) // rpg
+    A, W = bf(rnd((M, K), 11)), bf(rnd((N, K), 12, K ** -0.5))
+    bias, rowvec = rnd((N,), 13), rnd((G, N), 14)
+    R1, R2 = bf(rnd((M, N), 15)), bf(rnd((M, N), 16))
+    a1, a2 = rnd((G,), 17).abs() + 0.5, rnd((G,), 18)
+    grp = torch.arange(M) // rpg
+    ref = (A.float() @ W.float().T + bias + rowvec[grp] + R1.float()) * a1[grp, None] + a2[grp, None] * R2.float()
+    out = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K, bias=bias.to(dev), rowvec=rowvec.to(dev), ldrv=N,
+                   rows_per_group=rpg, R1=R1.to(dev), R2=R2.to(dev), a1=a1.to(dev), a2=a2.to(dev))
+    assert relerr(out, ref) < BF16_TOL
+    # GEGLU and the conv3x3 gather through the same tile
+    from hi3d_hip.pack import pack_conv3x3, pack_geglu
+    Nh = 320
+    Wg, bg = bf(rnd((2 * Nh, K), 19, K ** -0.5)).float(), rnd((2 * Nh,), 20)
+    h = A.float() @ Wg.T + bg
+    Wp, bp = pack_geglu(Wg, bg)
+    outg = ops.gemm(A.to(dev), Wp.to(dev), M=M, N=2 * Nh, K=K, bias=bp.to(dev), geglu=True)
+    assert relerr(outg, h[:, :Nh] * F.gelu(h[:, Nh:])) < BF16_TOL
+    Fr, H, Wd, Cin, Cout = 3, 12, 10, 64, 320
+    x, wc, bc = bf(rnd((Fr, Cin, H, Wd), 21)), bf(rnd((Cout, Cin, 3, 3), 22, (9 * Cin) ** -0.5)).float(), rnd((Cout,), 23)
+    refc = F.conv2d(x.float(), wc, bc, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin)
+    outc = ops.gemm(xt.to(dev), pack_conv3x3(wc, Cin).to(dev), M=Fr * H * Wd, N=Cout, K=9 * Cin, bias=bc.to(dev),
+                    conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0))
+    assert relerr(outc, refc) < BF16_TOL
+
+
 @pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
                                                          (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
                                                          (2, 9, 9, 64, 64, 2, 0)])
