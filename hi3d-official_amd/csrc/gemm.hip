@@ -16,6 +16,7 @@
 // so every lane ends up holding 4*NT *consecutive* output columns of one output
 // row: the epilogue reads residuals and writes results 8 bytes at a time.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -182,11 +183,14 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     w_off[nt] = A_BYTES + (wn * 16 * NT + (fr >> 2) * 4 * NT + nt * 4 + (fr & 3)) * 128;
   const int w_sw = (fr >> 1) & 7;
 
-  f32x4 acc[4][NT];
+  f32x4 acc[4][NT];                                // first written by the MFMAs of K step 0 (C = 0)
+  constexpr bool PEEL0 = NT <= 5 && AMODE == HI3D_A_DENSE;   // (wide tile, conv gathers: zero-fill instead -- peeling costs them registers / time)
+  if (!PEEL0) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // lane (fg, fr) owns rows m = m0 + wm*64 + mt*16 + fr, columns nb .. nb + 4*NT - 1
   const int nb = n0 + wn * 16 * NT + fg * 4 * NT;
 
@@ -233,11 +237,28 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
   // chunk c = tid + i*NTHR of a pass covers LDS row lr = c / CPR, columns 8*(c % CPR) .. +7;
   // its tile row is trow(lr) + pass * 16*MPP.
-  auto chunk_row = [&](int i) { const int lr = (tid + i * NTHR) / CPR; return (lr / (16 * MPP)) * 64 + (lr % (16 * MPP)); };
-  auto chunk_col = [&](int i) { return ((tid + i * NTHR) % CPR) * 8; };
-  auto chunk_ok = [&](int i, int pass) {
-    return tid + i * NTHR < HR * CPR && n0_out + chunk_col(i) < N_out && m0 + chunk_row(i) + pass * 16 * MPP < p.M;
+  // (computed once: the divisions by CPR would otherwise be redone in every pass)
+  int c_row[CH], c_col[CH], c_lds[CH];             // tile row at pass 0, column, byte offset in the slab
+  bool c_in[CH];                                   // chunk exists (inside the slab and left of N)
+  auto init_chunks = [&]() {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + i * NTHR, lr = c / CPR;
+      c_col[i] = (c - lr * CPR) * 8;
+      c_row[i] = (lr / (16 * MPP)) * 64 + (lr % (16 * MPP));
+      c_lds[i] = lr * LROW + c_col[i] * 4;
+      c_in[i] = c < HR * CPR && n0_out + c_col[i] < N_out;
+    }
   };
+  // dense GEMMs keep them in registers; the conv gathers have none to spare and recompute
+  constexpr bool PRECHUNK = AMODE == HI3D_A_DENSE;
+  if (PRECHUNK && NT <= 5) init_chunks();          // (wide tile: after the K loop)
+  auto chunk_lr = [&](int i) { return (tid + i * NTHR) / CPR; };
+  auto chunk_row = [&](int i) { if (PRECHUNK) return c_row[i]; const int lr = chunk_lr(i); return (lr / (16 * MPP)) * 64 + (lr % (16 * MPP)); };
+  auto chunk_col = [&](int i) { return PRECHUNK ? c_col[i] : ((tid + i * NTHR) % CPR) * 8; };
+  auto chunk_in = [&](int i) { return PRECHUNK ? c_in[i] : (tid + i * NTHR < HR * CPR && n0_out + chunk_col(i) < N_out); };
+  auto chunk_lds = [&](int i) { return PRECHUNK ? c_lds[i] : chunk_lr(i) * LROW + chunk_col(i) * 4; };
+  auto chunk_ok = [&](int i, int pass) { return chunk_in(i) && m0 + chunk_row(i) + pass * 16 * MPP < p.M; };
   constexpr int RP = (NT > 5) ? 1 : NPASS;          // R1 passes held in registers at a time
   u32x4 r1v[RP][CH], r2v[CH];
   auto fetch_residual = [&](const unsigned short* R, int ldr, int pass, u32x4 (&dst)[CH]) {
@@ -263,7 +284,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   if (NS != 1) issue(0, 0);
   if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  // one K step; `first` selects the C = 0 form of the MFMAs (saves zero-filling 16*NT registers)
+  auto kstep = [&](const int kt, auto first) {
+    constexpr bool FIRST = decltype(first)::value;
     if (NS == 1) {
       // single stage, 36-40 KiB LDS: 3 blocks per CU hide each other's loads and epilogues
       if (kt) __syncthreads();                // everyone is done reading the stage
@@ -309,12 +332,16 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTH; ++nt)
-            acc[mt][nh * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nh * NTH + nt], 0, 0, 0);
+            acc[mt][nh * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                wf[nt], xf[mt], (FIRST && PEEL0 && kh == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mt][nh * NTH + nt], 0, 0, 0);
       }
     }
     if (NS == 3) st = (st == 2) ? 0 : st + 1;
     else if (NS == 2) st ^= 1;
-  }
+  };
+  if (PEEL0) kstep(0, std::true_type{});
+  for (int kt = PEEL0 ? 1 : 0; kt < nk; ++kt) kstep(kt, std::false_type{});
+  if (PRECHUNK && NT > 5) init_chunks();
 
   // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
   // directly that is 64 scattered 8-byte requests per instruction, and the L2 request rate --
@@ -351,13 +378,13 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int lr = (tid + i * NTHR) / CPR, col = chunk_col(i);
+      const int col = chunk_col(i);
       const bool ok = chunk_ok(i, half);
       const int n = n0_out + col;
       const bool has8 = n + 8 <= N_out;
-      const char* tp = smem + lr * LROW + col * 4;
+      const char* tp = smem + chunk_lds(i);
       f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-      if (tid + i * NTHR < HR * CPR) { lo = *(const f32x4*)tp; hi = *(const f32x4*)(tp + 16); }
+      if (chunk_in(i)) { lo = *(const f32x4*)tp; hi = *(const f32x4*)(tp + 16); }
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       if (EPI == HI3D_EPI_AFFINE) {
         {                                            // bias + the tile's row vector (zeros when absent)
