@@ -315,6 +315,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       for (int pass = 0; pass < RP; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
     }
     const char* s = smem + st * STAGE;
+    __builtin_amdgcn_s_setprio(1);   // MFMA cluster first: measured +0.4 % on the dense shapes (hurts in attention)
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       constexpr int NTH = (NT > 5) ? NT / 2 : NT;   // weight fragments held at a time
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
                 wf[nt], xf[mt], (FIRST && PEEL0 && kh == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mt][nh * NTH + nt], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (NS == 3) st = (st == 2) ? 0 : st + 1;
     else if (NS == 2) st ^= 1;
   };
