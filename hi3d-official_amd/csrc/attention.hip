@@ -21,6 +21,7 @@
 //     layout directly; VALU kernel on v_dot2c_f32_bf16 (0.05 % of the step FLOPs, its
 //     cost is the q/k/v/o traffic).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -129,52 +130,100 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-  // Softmax bookkeeping in the log2 domain of the pre-scaled scores.  The common path does not
+  // Softmax bookkeeping in the log2 domain of the pre-scaled scores.  The common pass does not
   // compute the tile maximum: P = exp2(S - m_run) is formed as each 32-key score block leaves
-  // the MFMA (which already subtracted m_run, see negm), and only the row sums (needed anyway) are checked at the end of the tile.  Softmax
-  // is invariant to the shift, so any m_run that keeps P bounded is as good as the true
-  // maximum.  When a row sum exceeds SUM_MAX (or is not finite), and on the first tile, the
-  // tile is redone by the exact path: scores recomputed, true maximum, O and l rescaled.
-  // Both branches are wave-uniform.
+  // the MFMA (which already subtracted m_run, see negm), and only the row sums (needed anyway)
+  // are checked at the end of the tile.  Softmax is invariant to the shift, so any m_run that
+  // keeps P bounded is as good as the true maximum.  When a row sum exceeds SUM_MAX (or is not
+  // finite), on the first tile and on a ragged last tile, an exact pre-pass runs first: scores,
+  // true tile maximum, reference point / O / l moved in place -- and then the same common
+  // pass.  One P register set, one PV block (two sets would be merged by ~50 register moves
+  // per tile); all branches are wave-uniform.
   float m_run[QB], l_run[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) { m_run[qb] = 0.f; l_run[qb] = 0.f; }
   // -m_run in 16 equal registers per query block: the C operand of a tile's first score MFMA,
-  // so the subtraction costs no VALU instruction (rewritten only by the exact path)
+  // so the subtraction costs no VALU instruction (rewritten only by the exact pre-pass)
   f32x16 negm[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int ntile = (p.Skv + KV_TILE - 1) / KV_TILE;
-  issue(0, 0);
-  for (int j = 0; j < ntile; ++j) {
+  const int nfull = p.Skv / KV_TILE;                   // a ragged last tile (keys >= Skv to mask) is peeled off
+  // one key tile; RAGGED is a compile-time flag so that the mask's index arithmetic exists only
+  // in the peeled copy (left in the loop it was hoisted and ran on every tile: ~70 instructions)
+  auto tile = [&](const int j, auto ragged_tag) {
+    constexpr bool ragged = decltype(ragged_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (j + 1 < ntile) issue(j + 1, (j & 1) ^ 1);
-    const bool ragged = (j + 1) * KV_TILE > p.Skv;     // last tile with keys >= Skv to mask
+
+    // S^T - m = K Q^T - m for 32 keys x the wave's 64 query rows: every K fragment feeds QB MFMAs.
+    // lane registers: sc[qb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
+    auto scores = [&](const int kb, f32x16 (&sc)[QB]) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? negm[qb] : sc[qb], 0, 0, 0);
+      }
+      if (ragged) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
+            sc[qb][r] = (kv >= p.Skv) ? -INFINITY : sc[qb][r];
+          }
+      }
+    };
 
     bf16x8 pf[QB][4];
     float psum[QB];
-    bool redo = (j == 0) || ragged;                    // masking lives in the exact path only
-    if (!redo) {
+    bool exact = (j == 0) || ragged;
+    for (;;) {
+      if (exact) {
+        // exact pre-pass: move the rows' reference point to the true maximum seen so far
+        float mx[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mx[qb] = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x16 sc[QB];
+          scores(kb, sc);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[qb] = fmaxf(mx[qb], sc[qb][r]);
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float t = fmaxf(mx[qb], __shfl_xor(mx[qb], 32, 64));   // the row's other 32 keys of this tile
+          // t is relative to m_run (finite: every tile has >= 1 valid key); never move down,
+          // except to establish the reference on the first tile (O = l = 0 there)
+          const float d = (j == 0) ? t : fmaxf(t, 0.f);
+          const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
+          m_run[qb] += d;
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) negm[qb][r] -= d;     // in place (a fresh definition costs 32 moves per tile)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+        }
+      }
+      // common pass
       hi3d_f2 ps[QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) ps[qb] = hi3d_f2{0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        // S^T = K Q^T for 32 keys x the wave's 64 query rows: every K fragment feeds QB MFMAs
         f32x16 sc[QB];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
-            sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? negm[qb] : sc[qb], 0, 0, 0);
-        }
-        // lane registers: sc[qb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
+        scores(kb, sc);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
@@ -195,61 +244,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
       bool ok = true;
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) { psum[qb] = ps[qb][0] + ps[qb][1]; ok = ok && (psum[qb] <= SUM_MAX); }   // NaN / inf fail too
-      redo = !__all(ok);
-    }
-    if (redo) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        f32x16 sc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
-            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
-          }
-          if (ragged) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
-              sc[kb][r] = (kv >= p.Skv) ? -INFINITY : sc[kb][r];
-            }
-          }
-        }
-        float mx = sc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // the row's other 32 keys of this tile
-        // finite: every tile has >= 1 valid key.  The reference point never moves down.
-        const float m_new = (j == 0) ? mx : fmaxf(m_run[qb], mx);
-        const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-        m_run[qb] = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
-        float acc = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            union { bf16x8 v; unsigned int u[4]; } pk;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float e0 = __builtin_amdgcn_exp2f(sc[kb][half * 8 + 2 * t] - m_new);
-              const float e1 = __builtin_amdgcn_exp2f(sc[kb][half * 8 + 2 * t + 1] - m_new);
-              acc += e0 + e1;
-              pk.u[t] = pack_bf16x2(e0, e1);
-            }
-            pf[qb][kb * 2 + half] = pk.v;
-          }
-        psum[qb] = acc;
-      }
+      if (exact || __all(ok)) break;
+      exact = true;                                    // rare: redo this tile through the pre-pass
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum[qb];
@@ -269,7 +265,10 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { k_ptr[ks] += stage_step; v_ptr[ks] += stage_step; }
     stage_step = -stage_step;
-  }
+  };
+  issue(0, 0);
+  for (int j = 0; j < nfull; ++j) tile(j, std::false_type{});
+  if (nfull < ntile) tile(nfull, std::true_type{});
 
   // ---- finish: both half-waves hold partial row sums of the same query row
 #pragma unroll
