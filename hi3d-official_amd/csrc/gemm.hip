@@ -259,25 +259,27 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   auto chunk_in = [&](int i) { return PRECHUNK ? c_in[i] : (tid + i * NTHR < HR * CPR && n0_out + chunk_col(i) < N_out); };
   auto chunk_lds = [&](int i) { return PRECHUNK ? c_lds[i] : chunk_lr(i) * LROW + chunk_col(i) * 4; };
   auto chunk_ok = [&](int i, int pass) { return chunk_in(i) && m0 + chunk_row(i) + pass * 16 * MPP < p.M; };
-  constexpr int RP = (NT > 5) ? 1 : NPASS;          // R1 passes held in registers at a time
+  constexpr int RP = NPASS;                         // R1 passes held in registers (narrow tiles)
   u32x4 r1v[RP][CH], r2v[CH];
-  auto fetch_residual = [&](const unsigned short* R, int ldr, int pass, u32x4 (&dst)[CH]) {
+  // chunk i of pass `pass` of a residual tile (row-contiguous 16 bytes; void chunks read zeros)
+  auto fetch_chunk = [&](const unsigned short* R, int ldr, int pass, int i) -> u32x4 {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(R + (long)m0 * ldr + n0_out), 0, 0x7fffffff, 0x00020000);
     const int so = pass * 16 * MPP * ldr * 2;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int col = chunk_col(i);
-      const bool has8 = n0_out + col + 8 <= N_out;
-      const unsigned vo = chunk_ok(i, pass) ? (unsigned)((chunk_row(i) * ldr + col) * 2) : INV;
-      if (has8 && p.vec8) {
-        dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
-      } else {                                      // 8-byte pieces: narrow or unaligned rows
-        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
-        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, has8 ? vo + 8 : INV, so, 0);
-        dst[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-      }
-    }
+    const int col = chunk_col(i);
+    const bool has8 = n0_out + col + 8 <= N_out;
+    const unsigned vo = chunk_ok(i, pass) ? (unsigned)((chunk_row(i) * ldr + col) * 2) : INV;
+    if (has8 && p.vec8) return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);   // 8-byte pieces: narrow or unaligned rows
+    const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, has8 ? vo + 8 : INV, so, 0);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
   };
+  auto fetch_residual = [&](const unsigned short* R, int ldr, int pass, u32x4 (&dst)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) dst[i] = fetch_chunk(R, ldr, pass, i);
+  };
+  // The wide tile (NT > 5) has 160 accumulator registers and none to park residual slabs in:
+  // it loads each residual chunk where it is consumed (latency exposed; its K loops are long).
+  constexpr bool RES_EARLY = NT <= 5;
 
   const int nk = p.K / BK;
   const int pf_kt = nk >= 2 ? nk - 2 : 0;
@@ -350,8 +352,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // not bandwidth -- bounds every short-K GEMM.  So the fp32 tile goes through LDS (the
   // ring is free now), NPASS slabs of HR rows, and all global traffic (residual loads,
   // stores) is issued row-contiguous, 16 bytes per lane.
-  if (EPI == HI3D_EPI_AFFINE && p.R2) fetch_residual(p.R2, p.ldr2, 0, r2v);
-  if (EPI == HI3D_EPI_AFFINE && NT > 5 && p.R1) fetch_residual(p.R1, p.ldr1, 0, r1v[0]);   // 160 accumulator registers: no room earlier
+  if (EPI == HI3D_EPI_AFFINE && RES_EARLY && p.R2) fetch_residual(p.R2, p.ldr2, 0, r2v);
   const int osz = p.out_fp32 ? 4 : 2;
   const __amdgpu_buffer_rsrc_t rsO =
       __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           if (has8) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
         }
         if (p.R1) {
-          const u32x4 r = r1v[half % RP][i];
+          const u32x4 r = RES_EARLY ? r1v[half % RP][i] : fetch_chunk(p.R1, p.ldr1, half, i);
           v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
           v[4] += bf16_to_f32(r[2] & 0xffff); v[5] += bf16_to_f32(r[2] >> 16); v[6] += bf16_to_f32(r[3] & 0xffff); v[7] += bf16_to_f32(r[3] >> 16);
         }
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           for (int j = 0; j < 8; ++j) v[j] *= s1; }
         if (p.R2) {
           const float s2 = ugrp ? ts2 : (p.a2 ? p.a2[grp] : 1.0f);
-          const u32x4 r = r2v[i];
+          const u32x4 r = RES_EARLY ? r2v[i] : fetch_chunk(p.R2, p.ldr2, half, i);
           v[0] += s2 * bf16_to_f32(r[0] & 0xffff); v[1] += s2 * bf16_to_f32(r[0] >> 16); v[2] += s2 * bf16_to_f32(r[1] & 0xffff); v[3] += s2 * bf16_to_f32(r[1] >> 16);
           v[4] += s2 * bf16_to_f32(r[2] & 0xffff); v[5] += s2 * bf16_to_f32(r[2] >> 16); v[6] += s2 * bf16_to_f32(r[3] & 0xffff); v[7] += s2 * bf16_to_f32(r[3] >> 16);
         }
@@ -433,8 +434,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         }
       }
     }
-    if (EPI == HI3D_EPI_AFFINE && p.R2 && half + 1 < NPASS) fetch_residual(p.R2, p.ldr2, half + 1, r2v);
-    if (EPI == HI3D_EPI_AFFINE && p.R1 && half + RP < NPASS) fetch_residual(p.R1, p.ldr1, half + RP, r1v[half % RP]);
+    if (EPI == HI3D_EPI_AFFINE && RES_EARLY && p.R2 && half + 1 < NPASS) fetch_residual(p.R2, p.ldr2, half + 1, r2v);
     if (half + 1 < NPASS) __syncthreads();
   }
 #endif
