@@ -217,10 +217,11 @@ def main():
 def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
     """Oracle (oracle/hi3d_oracle.py, fp32 torch CPU kernels = the reference's CPU path
     restated) timed on this box's host cores on a bounded sample of the same step: the
-    full-width UNet at T=4, latent 16x16, extrapolated to the full step by executed FLOPs."""
+    full-width UNet at T=8, latent 16x16 (10-20 s of CPU work), extrapolated to the full step by
+    executed FLOPs."""
     from hi3d_hip import ops
     from oracle import hi3d_oracle as O
-    T, hw = 4, 16
+    T, hw = 8, 16
     g = torch.Generator().manual_seed(0)
     x = torch.randn((2 * T, cfg["in_channels"], hw, hw), generator=g)
     ts = torch.full((2 * T,), 0.25 * 1.5)
@@ -239,7 +240,7 @@ def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
     cpu_tflops = sample_flops / dt / 1e12
     full = step_flops_exec if step_flops_exec else step_tf * 1e12
     return {"value": round(cpu_tflops * 1e12 / full, 6), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 UNet forward, full width, T=4, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP in "
+            "sample": f"oracle fp32 UNet forward, full width, T=8, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP in "
                       f"{dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {cores} threads), extrapolated to the "
                       f"{full / 1e12:.1f} TFLOP executed per full step",
             "seconds": round(dt, 2)}

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Build profiles/traffic_<cfg>.json (HBM bytes per launch of the dominant kernels) from the two
+pmc_traffic.py summaries of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.
+
+usage: make_traffic_json.py FETCH.csv WRITE.csv out.json
+
+FETCH_SIZE is doubled: on gfx950 it counts half of the bytes of 16 B/lane streams (see
+MI355X_MICROARCH.md; calibrated here on layernorm_kernel<1>, which reads 327,680 KB per launch at the
+128^2 level and reports 163,9xx KB).  Both counters are in KB."""
+import csv
+import json
+import sys
+
+
+def load(path):
+    rows = {}
+    with open(path) as fh:
+        next(fh)                       # "counter,NAME"
+        for r in csv.DictReader(fh):
+            rows[r["kernel"]] = (int(r["dispatches"]), float(r["sum"]))
+    return rows
+
+
+def family(rows, prefix):
+    n = sum(d for k, (d, s) in rows.items() if k.startswith(prefix))
+    s = sum(s for k, (d, s) in rows.items() if k.startswith(prefix))
+    return n, s
+
+
+def main():
+    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    res = {}
+    for fam in ("gemm_bf16_kernel", "attn_d64_kernel"):
+        nf, sf = family(fetch, fam)
+        nw, sw = family(write, fam)
+        n = max(nf, nw)
+        res[fam] = {
+            "bytes_per_launch": int((2.0 * sf + sw) * 1024 / n),
+            "unit": "B",
+            "launches_profiled": n,
+            "fetch_KB_x2_corrected": int(2.0 * sf),
+            "write_KB": int(sw),
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
+                      "FETCH_SIZE doubled (gfx950 half-count for 16 B/lane streams, calibrated on layernorm)",
+        }
+    cal = fetch.get("layernorm_kernel<1>")
+    if cal:
+        res["calibration"] = {"layernorm_kernel<1>_fetch_KB_per_launch_reported": cal[1] / cal[0],
+                              "bytes_actually_read_KB": 327680}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
