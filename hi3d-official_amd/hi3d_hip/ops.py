@@ -295,3 +295,24 @@ def time_mix_small(x, w, b, B, T, H, W, C):
     out = torch.empty((B * T, C, H, W), device=x.device, dtype=torch.float32)
     _l.check(_lib.hi3d_time_mix_small(_p(x), _p(w), _p(b), _p(out), B, T, H * W, C, x.stride(0), _stream()), "hi3d_time_mix_small")
     return out
+
+
+FFN_FUSED_WIDTHS = (320,)   # channel counts hi3d_ffn_geglu is built for
+
+
+def ffn_geglu(x, w1, b1, w2, b2, *, M, C, R1=None, R2=None, a1=None, a2=None, rows_per_group=1, out=None):
+    """out[M, C] = (GEGLU(x w1^T + b1) w2^T + b2 + R1) [* a1 + a2 * R2] with the 4C hidden tensor kept on
+    the CU (one launch instead of the GEGLU GEMM + the second GEMM).  See include/hi3d_hip.h."""
+    _chk_dev(x, w1, b1, w2, b2, R1, R2, a1, a2, out)
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_ffn_geglu(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(R1), _p(R2), _p(a1), _p(a2), _p(out),
+                                 M, C, x.stride(0), out.stride(0), R1.stride(0) if R1 is not None else 0,
+                                 R2.stride(0) if R2 is not None else 0, rows_per_group, _stream()), "hi3d_ffn_geglu")
+    if prof:
+        nres = (R1 is not None) + (R2 is not None)
+        prof.end("ffn_fused", 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C,
+                 2.0 * (M * C * (2 + nres) + 12 * C * C), t0, detail=f"M={M} C={C}")
+    return out

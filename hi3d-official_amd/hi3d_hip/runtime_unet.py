@@ -21,6 +21,8 @@ reference's parameter names (state_dict compatibility).  This runtime is what ru
     Those vectors and the frame-position embeddings depend only on the conditioning,
     so they are cached across the 25 sampler steps.
 """
+import os
+
 import torch
 
 from . import ops, pack
@@ -76,6 +78,8 @@ class UNetRuntime:
         if cfg["in_channels"] > CIN_PAD:
             raise ops._l.Hi3dError("UNetRuntime: in_channels > 64 not supported")
         self.layout = unet_layout(cfg)
+        # HI3D_FUSED_FFN=0 falls back to the two-GEMM feed-forward (A/B switch; both are HIP paths)
+        self.fused_ffn = os.environ.get("HI3D_FUSED_FFN", "1") != "0"
         self._cond_cache = None
         self._pos_cache = {}
         self._pack(state_dict, prefix)
@@ -237,26 +241,31 @@ class UNetRuntime:
         h = ops.gemm(a, W[sp + ".o.w"], M=M, N=C, K=C, bias=W[sp + ".o.b"], R1=h,
                      rowvec=cond[sp], rows_per_group=S)                     # + attn1 + attn2 (one token)
         n = ops.layernorm(h, W[sp + ".norm3.g"], W[sp + ".norm3.b"], M, C)
-        gg = ops.gemm(n, W[sp + ".ff.1.w"], M=M, N=8 * C, K=C, bias=W[sp + ".ff.1.b"], geglu=True)
-        h = ops.gemm(gg, W[sp + ".ff.2.w"], M=M, N=C, K=4 * C, bias=W[sp + ".ff.2.b"], R1=h)
+        h = self._ff(n, sp + ".ff", M, C, R1=h)
         # --- temporal block (video_attention.py:109-140), rows stay in (b t) s order
         xm = torch.empty_like(h)
         n = ops.layernorm(h, W[tp + ".norm_in.g"], W[tp + ".norm_in.b"], M, C, addvec=self._pos_emb(p, C, B, T),
                           rows_per_group=S, sum_out=xm)                      # xm = h + frame-position emb
-        gg = ops.gemm(n, W[tp + ".ff_in.1.w"], M=M, N=8 * C, K=C, bias=W[tp + ".ff_in.1.b"], geglu=True)
-        xm = ops.gemm(gg, W[tp + ".ff_in.2.w"], M=M, N=C, K=4 * C, bias=W[tp + ".ff_in.2.b"], R1=xm)
+        xm = self._ff(n, tp + ".ff_in", M, C, R1=xm)
         n = ops.layernorm(xm, W[tp + ".norm1.g"], W[tp + ".norm1.b"], M, C)
         qkv = ops.gemm(n, W[tp + ".qkv.w"], M=M, N=3 * C, K=C)
         a = ops.attention_temporal_fused_qkv(qkv, B, T, S, Hh)
         xm = ops.gemm(a, W[tp + ".o.w"], M=M, N=C, K=C, bias=W[tp + ".o.b"], R1=xm,
                       rowvec=cond[tp], rows_per_group=T * S)
         n = ops.layernorm(xm, W[tp + ".norm3.g"], W[tp + ".norm3.b"], M, C)
-        gg = ops.gemm(n, W[tp + ".ff.1.w"], M=M, N=8 * C, K=C, bias=W[tp + ".ff.1.b"], geglu=True)
         i = self.mix_index[p]
         # AlphaBlender: alpha*h + (1-alpha)*(ff(..)+xm)                      (video_attention.py:290-294)
-        h = ops.gemm(gg, W[tp + ".ff.2.w"], M=M, N=C, K=4 * C, bias=W[tp + ".ff.2.b"], R1=xm,
-                     a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=S)
+        h = self._ff(n, tp + ".ff", M, C, R1=xm, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=S)
         return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x)
+
+    def _ff(self, n, key, M, C, **epi):
+        """FeedForward(glu=True) (attention.py:83-119) + the caller's residual / blend epilogue: one fused
+        launch where hi3d_ffn_geglu is built for the width, else GEGLU GEMM + second GEMM."""
+        W = self.W
+        if C in ops.FFN_FUSED_WIDTHS and self.fused_ffn:
+            return ops.ffn_geglu(n, W[key + ".1.w"], W[key + ".1.b"], W[key + ".2.w"], W[key + ".2.b"], M=M, C=C, **epi)
+        gg = ops.gemm(n, W[key + ".1.w"], M=M, N=8 * C, K=C, bias=W[key + ".1.b"], geglu=True)
+        return ops.gemm(gg, W[key + ".2.w"], M=M, N=C, K=4 * C, bias=W[key + ".2.b"], **epi)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

@@ -251,6 +251,22 @@ int hi3d_v02_blend(float* lat, const float* noise, const float* z, int64_t n, fl
 int hi3d_time_mix_small(const float* x, const float* w, const float* b, float* out, int32_t B,
                         int32_t T, int32_t HW, int32_t C, int32_t ldx, void* stream);
 
+/* Fused GEGLU feed-forward (FeedForward, sgm/modules/attention.py:83-119, as used by
+ * BasicTransformerBlock attention.py:522-537 and VideoTransformerBlock video_attention.py:
+ * 109-140; the optional tail is the AlphaBlender of the temporal block, video_attention.py:
+ * 290-294):
+ *   out[M][C] = ( GEGLU(x w1^T + b1) w2^T + b2 + r1 ) [ * a1[g] + a2[g] * r2 ],   g = row / rows_per_group
+ * x [M][ldx] bf16; w1 [8C][C] bf16 with rows interleaved [x0,x1,g0,g1] and b1 [8C] fp32 in the
+ * same order (exactly the operands of hi3d_gemm_bf16 with HI3D_EPI_GEGLU); w2 [C][4C] bf16;
+ * b2 [C] fp32; r1 / r2 [M][ld] bf16 or NULL; a1 / a2 per-group fp32 or NULL.  The 4C-wide
+ * hidden tensor stays on the CU.  Built for C = 320 (the 128^2 / 64^2-token level where the two
+ * GEMMs are bound by that tensor's HBM round trip); other widths return HI3D_ESHAPE and
+ * the caller issues the two GEMMs.                                                      */
+int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                   const void* r1, const void* r2, const float* a1, const float* a2, void* out,
+                   int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
+                   int32_t rows_per_group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,38 @@ def test_gemm_tile_variants(dev, variant, monkeypatch):
     assert relerr(outc, refc) < BF16_TOL
 
 
+@pytest.mark.parametrize("M,blend", [(300, False), (1000, True), (128, False)])
+def test_ffn_geglu_fused(dev, M, blend):
+    """Fused feed-forward vs fp32 torch: GEGLU(x W1^T + b1) W2^T + b2 + R1 [AlphaBlender tail]."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_geglu, pack_linear
+    C, rpg = 320, 128
+    G = (M + rpg - 1) // rpg
+    x = bf(rnd((M, C), 31))
+    w1, b1 = bf(rnd((8 * C, C), 32, C ** -0.5)).float(), rnd((8 * C,), 33)
+    w2, b2 = bf(rnd((C, 4 * C), 34, (4 * C) ** -0.5)).float(), rnd((C,), 35)
+    R1, R2 = bf(rnd((M, C), 36)), bf(rnd((M, C), 37))
+    a1, a2 = rnd((G,), 38).abs() + 0.5, rnd((G,), 39)
+    h = x.float() @ w1.T + b1
+    hg = bf(h[:, :4 * C] * F.gelu(h[:, 4 * C:])).float()          # the hidden tensor is bf16 in both paths
+    ref = hg @ w2.T + b2 + R1.float()
+    kw = {}
+    if blend:
+        grp = torch.arange(M) // rpg
+        ref = ref * a1[grp, None] + a2[grp, None] * R2.float()
+        kw = dict(R2=R2.to(dev), a1=a1.to(dev), a2=a2.to(dev), rows_per_group=rpg)
+    w1p, b1p = pack_geglu(w1, b1)
+    out = ops.ffn_geglu(x.to(dev), w1p.to(dev), b1p.to(dev), pack_linear(w2).to(dev), b2.to(dev), M=M, C=C, R1=R1.to(dev), **kw)
+    assert out.shape == (M, C)
+    assert relerr(out, ref) < BF16_TOL
+    # and against the unfused HIP path (same packed operands)
+    gg = ops.gemm(x.to(dev), w1p.to(dev), M=M, N=8 * C, K=C, bias=b1p.to(dev), geglu=True)
+    two = ops.gemm(gg, pack_linear(w2).to(dev), M=M, N=C, K=4 * C, bias=b2.to(dev), R1=R1.to(dev), **kw)
+    assert relerr(out, two.float()) < 6e-3
+    with pytest.raises(ops._l.Hi3dError):
+        ops.ffn_geglu(x.to(dev), w1p.to(dev), b1p.to(dev), pack_linear(w2).to(dev), b2.to(dev), M=M, C=640)
+
+
 @pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
                                                          (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
                                                          (2, 9, 9, 64, 64, 2, 0)])

@@ -102,7 +102,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -144,3 +144,27 @@ def bench_attn_one():
 
 if len(sys.argv) > 1 and sys.argv[1] == "attn1":
     bench_attn_one()
+
+
+def bench_ffn():
+    """kbench.py ffn : fused GEGLU feed-forward vs GEGLU GEMM + second GEMM at the 320-channel level."""
+    C = 320
+    for M in (524288, 131072):
+        x, R1 = rb(M, C), rb(M, C)
+        w1, w2 = rb(8 * C, C), rb(C, 4 * C)
+        b1, b2 = torch.randn(8 * C, device=dev), torch.randn(C, device=dev)
+        out = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
+        gg = torch.empty((M, 4 * C), device=dev, dtype=torch.bfloat16)
+        fl = 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C
+        ms = timeit(lambda: ops.ffn_geglu(x, w1, b1, w2, b2, M=M, C=C, R1=R1, out=out))
+        print(f"  fused   M={M:7d}: {ms:8.3f} ms {fl / ms / 1e9:8.1f} TFLOP/s")
+
+        def two():
+            ops.gemm(x, w1, M=M, N=8 * C, K=C, bias=b1, geglu=True, out=gg)
+            ops.gemm(gg, w2, M=M, N=C, K=4 * C, bias=b2, R1=R1, out=out)
+        ms = timeit(two)
+        print(f"  2 GEMMs M={M:7d}: {ms:8.3f} ms {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "ffn":
+    bench_ffn()
