@@ -13,12 +13,15 @@
 //     hg  [128 x 64]   = value * gelu(gate)  -> bf16 -> LDS, already in A-operand layout
 //     acc2[128 x 320] += hg . W2[:, chunk]^T                 (K = 64)
 //
-// so the hidden tensor never leaves the CU and each 128-row tile is loaded once.  The X tile
-// stays resident in LDS (80 KiB); W1 streams through a 2-slot ring of 16 KiB K-steps, the
-// chunk's W2 slab (40 KiB) lands during the first GEMM, and hg reuses ring slot 1.  155,648 B
-// of LDS, one block (4 waves, 64 x 64 / 64 x 160 wave tiles) per CU; both accumulators live in
-// registers (64 + 160 per lane).  Operand layouts, swizzles and the swapped-MFMA column order
-// are those of gemm.hip, so the packed weights are shared with the unfused path.
+// so the hidden tensor never leaves the CU and each 128-row tile is loaded once.  One block of
+// 4 waves (64 x 64 / 64 x 160 wave tiles) per CU and one wave per SIMD, which buys 512
+// registers per lane: the wave's slice of X (160), both accumulators (64 + 160) and the
+// operand fragments all live there, and LDS (147,456 B) belongs to the weight streams -- W1
+// through a 3-slot ring of 16 KiB K-steps running two steps ahead across chunk boundaries,
+// W2 double-buffered a whole chunk ahead, plus the 16 KiB hg slab.  With a single wave per
+// SIMD nothing hides a load, so every wait is a counted vmcnt that leaves the younger streams
+// in flight.  Operand layouts, swizzles and the swapped-MFMA column order are those of
+// gemm.hip, so the packed weights are shared with the unfused path.
 #include "common.h"
 #include <stdlib.h>
 
@@ -40,20 +43,19 @@ constexpr int FBM = 128;                   // rows per block
 constexpr int FHC = 64;                    // hidden columns per chunk
 constexpr int NCHUNK = FH / FHC;           // 20
 constexpr int KX = FC / 64;                // K steps of the first GEMM
-constexpr int SLAB = FBM * 128;            // one 64-wide K slab of the X tile / of hg: 16 KiB
-constexpr int XS_BYTES = KX * SLAB;        // 80 KiB
+constexpr int SLAB = FBM * 128;            // the hg slab: 128 rows x 64 k, 16 KiB
 constexpr int W1_STAGE = 2 * FHC * 128;    // 128 packed rows x 64 k: 16 KiB
+constexpr int W1_SLOTS = 3;
 constexpr int W2_BYTES = FC * 128;         // 320 rows x 64 k: 40 KiB
-constexpr int FFN_LDS = XS_BYTES + 2 * W1_STAGE + W2_BYTES;
-constexpr int X_OPS = KX * 4, W1_OPS = 4, W2_OPS = 10;   // LDS-DMA instructions per wave
+constexpr int FFN_LDS = W1_SLOTS * W1_STAGE + 2 * W2_BYTES + SLAB;   // 147,456 B
+constexpr int W1_OPS = 4, W2_OPS = 10, B1_OPS = 4;   // memory instructions per wave
 
 __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams p) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const XS = smem;
-  char* const W1R = smem + XS_BYTES;
-  char* const HG = W1R + W1_STAGE;           // ring slot 1 doubles as the hg slab
-  char* const W2S = W1R + 2 * W1_STAGE;
+  char* const W1R = smem;                                  // 3-slot ring of W1 K-steps
+  char* const W2S = smem + W1_SLOTS * W1_STAGE;            // two W2 slabs (chunk parity)
+  char* const HG = W2S + 2 * W2_BYTES;                     // hg slab
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,15 +65,28 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
   const int m0 = blockIdx.x * FBM;
   constexpr unsigned INV = 0x80000000u;
 
-  // ---- loaders (per-lane byte offsets fixed for the whole kernel; K / chunk walk in the scalar offset)
+  // ---- the wave's 64 x 320 slice of X lives in registers for the whole kernel, already in
+  // MFMA B-operand layout (lane (fr, fg): row fr of each 16-row block, k = 32*j + 8*fg .. +7):
+  // 160 VGPRs, which one wave per SIMD can afford and which leaves LDS to the weight streams
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)m0 * p.ldx * 2), 0, 0x7fffffff, 0x00020000);
+  bf16x8 xr[2 * KX][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int r = wm * 64 + mt * 16 + fr;
+    const unsigned vo = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + fg * 16) : INV;
+#pragma unroll
+    for (int j = 0; j < 2 * KX; ++j) {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, j * 64, 0);
+      xr[j][mt] = __builtin_bit_cast(bf16x8, t);
+    }
+  }
+
+  // ---- weight loaders (per-lane byte offsets fixed; K step / chunk walk in the scalar offset)
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, 0x7fffffff, 0x00020000);
-  unsigned x_voff[4], w1_voff[4], w2_voff[10];
+  unsigned w1_voff[4], w2_voff[10];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (w * 4 + i) * 8 + lrow;
-    x_voff[i] = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + ((lslot ^ ((r >> 1) & 7)) << 4)) : INV;
     const int j = (w + 4 * i) * 8 + lrow, jw = j & 63;            // packed W1 row of the chunk
     const int fi = (jw >> 4) * 4 + (jw & 3);                       // MFMA row index that reads it
     w1_voff[i] = (unsigned)(j * FC * 2 + ((lslot ^ ((fi >> 1) & 7)) << 4));
@@ -82,13 +97,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
     const int fi = (jw / 40) * 4 + (jw & 3);
     w2_voff[i] = (unsigned)(j * FH * 2 + ((lslot ^ ((fi >> 1) & 7)) << 4));
   }
-  auto issue_x = [&]() {
-#pragma unroll
-    for (int kt = 0; kt < KX; ++kt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (LDS_AS void*)(XS + kt * SLAB + (w * 4 + i) * 1024), 16, x_voff[i], kt * 128, 0, 0);
-  };
+  // W1 K-step s = 5*chunk + k: rows 128*chunk .. +127 of the packed matrix, k columns 64*k .. +63
   auto issue_w1 = [&](int c, int k, int slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -98,12 +107,12 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
   auto issue_w2 = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 10; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (LDS_AS void*)(W2S + (w + 4 * i) * 1024), 16, w2_voff[i], c * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (LDS_AS void*)(W2S + (c & 1) * W2_BYTES + (w + 4 * i) * 1024), 16, w2_voff[i], c * 128, 0, 0);
   };
 
   // ---- fragment read offsets
   const int f_sw = (fr >> 1) & 7;
-  const int x_off = (wm * 64 + fr) * 128;                                   // + mt * 2048
+  const int x_off = (wm * 64 + fr) * 128;                                   // + mt * 2048   (hg slab)
   const int w1_off = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * 128;           // + nt * 512
   const int w2_off = (wn * 160 + (fr >> 2) * 40 + (fr & 3)) * 128;          // + nt * 512
   // this lane's packed columns of a chunk: wn*64 + fg*16 + nt*4 .. +3  (= hidden columns wn*32 + fg*8 + nt*2, +1)
@@ -117,46 +126,67 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue_x();
-  issue_w1(0, 0, 0);
   f32x4 b1v[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) b1v[nt] = *(const f32x4*)(b1p + nt * 4);
+  issue_w2(0);
+  issue_w1(0, 0, 0);
+  issue_w1(0, 1, 1);
 
+  int slot = 0;                                  // ring slot of the current K step
   for (int c = 0; c < NCHUNK; ++c) {
-    // every wave is done with the previous chunk's second GEMM: W2S and hg are free
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_w2(c);
     f32x4 acc1[4][4];
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-      // W1 stage (c, k) must have landed (with the X tile on the first chunk); at k = 0 the W2 slab
-      // just requested may stay in flight.  vmcnt retires in order.
-      if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2_OPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // Stage s = (c, k) must have landed.  Loads retire in order; younger than stage s are stage
+      // s+1 (4 ops) and whatever the previous step issued after it: the next chunk's W2 slab
+      // (after k = 0) or its bias registers (after k = 1).
+      if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_OPS + W2_OPS) : "memory");
+      else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_OPS + B1_OPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_OPS) : "memory");
+      __builtin_amdgcn_s_barrier();              // ... for every wave; slot (s-1)%3 is free again
       asm volatile("" ::: "memory");
-      if (k + 1 < KX) issue_w1(c, k + 1, (k + 1) & 1);
-      const char* xs = XS + k * SLAB;
-      const char* ws = W1R + (k & 1) * W1_STAGE;
+      {                                          // stage s+2 -> the slot stage s-1 used
+        const int k2 = k + 2 < KX ? k + 2 : k + 2 - KX, c2 = k + 2 < KX ? c : c + 1;
+        const int slot2 = slot == 0 ? 2 : slot - 1;
+        if (c2 < NCHUNK) issue_w1(c2, k2, slot2);
+        else {                                   // keep the per-step op count uniform for the vmcnt arithmetic
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (LDS_AS void*)(W1R + slot2 * W1_STAGE + (w + 4 * i) * 1024), 16, INV, 0, 0, 0);
+        }
+      }
+      if (k == 0) {                              // next chunk's W2 slab into the other buffer
+        if (c + 1 < NCHUNK) issue_w2(c + 1);
+        else {
+#pragma unroll
+          for (int i = 0; i < 10; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (LDS_AS void*)(W2S + ((c + 1) & 1) * W2_BYTES + (w + 4 * i) * 1024), 16, INV, 0, 0, 0);
+        }
+      }
+      if (k == 1) {                              // next chunk's bias columns (b1v was consumed by step 0; the last chunk re-reads its own)
+        const int cn = c + 1 < NCHUNK ? c + 1 : c;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b1v[nt] = *(const f32x4*)(b1p + cn * (2 * FHC) + nt * 4);
+      }
+      const char* ws = W1R + slot * W1_STAGE;
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         const int cx = ((kh * 4 + fg) ^ f_sw) << 4;
-        bf16x8 xf[4], wf[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(xs + x_off + mt * 2048 + cx);
+        bf16x8 wf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(ws + w1_off + nt * 512 + cx);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], (k == 0 && kh == 0) ? b1v[nt] : acc1[mt][nt], 0, 0, 0);
+            acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xr[2 * k + kh][mt], (k == 0 && kh == 0) ? b1v[nt] : acc1[mt][nt], 0, 0, 0);
       }
+      slot = slot == 2 ? 0 : slot + 1;
     }
     // GEGLU: value * gelu(gate) -> 8 consecutive hidden columns per lane and row = one 16-byte
-    // chunk of the hg slab, written in the swizzled A-operand layout
+    // chunk of the hg slab, written in the swizzled A-operand layout.  (Every wave passed the
+    // K-step barriers of this chunk after its previous hg reads, so the slab is free.)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       unsigned int u[4];
@@ -168,13 +198,12 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
       }
       *(uint4*)(hg_w + mt * 2048) = make_uint4(u[0], u[1], u[2], u[3]);
     }
-    __syncthreads();                           // hg visible; ring slot 0 no longer read
-    if (c + 1 < NCHUNK) {
-      issue_w1(c + 1, 0, 0);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) b1v[nt] = *(const f32x4*)(b1p + (c + 1) * (2 * FHC) + nt * 4);
-    }
-    // acc2 += hg . W2[:, chunk]^T   (the slab landed: the vmcnt(0) of K step 1 covered it)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // hg visible (no vmcnt drain: the weight streams stay in flight)
+    asm volatile("" ::: "memory");
+    // acc2 += hg . W2[:, chunk]^T   (the slab was requested a whole chunk ago and every later
+    // wait covered it)
+    const char* w2s = W2S + (c & 1) * W2_BYTES;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       const int cx = ((kh * 4 + fg) ^ f_sw) << 4;
@@ -185,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_c320_kernel(const FfnParams 
       for (int nh = 0; nh < 2; ++nh) {
         bf16x8 wf[5];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) wf[nt] = *(const bf16x8*)(W2S + w2_off + (nh * 5 + nt) * 512 + cx);
+        for (int nt = 0; nt < 5; ++nt) wf[nt] = *(const bf16x8*)(w2s + w2_off + (nh * 5 + nt) * 512 + cx);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
