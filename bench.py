@@ -174,7 +174,7 @@ def main():
                 log(f"[bench]   {fam:60s} {d['ms'] / a.steps:8.3f} ms/step {d['launches'] // a.steps:4d}x "
                     f"{d['ms'] / d['launches']:7.3f} ms each {tf:7.1f} TFLOP/s {gbs:7.0f} GB/s(alg)")
         # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
-        g = [d for f, d in summ.items() if f.startswith("gemm_")]
+        g = [d for f, d in summ.items() if f.startswith("gemm_")]   # (the fused feed-forward kernel is listed on its own line)
         g_ms, g_fl, g_n = sum(d["ms"] for d in g), sum(d["flops"] for d in g), sum(d["launches"] for d in g)
         at = summ.get("attn_d64", dict(ms=0.0, flops=0.0, launches=1))
         dom_is_gemm = g_ms >= at["ms"]
