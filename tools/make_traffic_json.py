@@ -30,7 +30,7 @@ def family(rows, prefix):
 def main():
     fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
     res = {}
-    for fam in ("gemm_bf16_kernel", "attn_d64_kernel"):
+    for fam in ("gemm_bf16_kernel", "attn_d64_kernel", "ffn_geglu_c320_kernel"):
         nf, sf = family(fetch, fam)
         nw, sw = family(write, fam)
         n = max(nf, nw)
