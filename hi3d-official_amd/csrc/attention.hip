@@ -42,6 +42,9 @@ constexpr int ATT_STAGE = 2 * KV_TILE * 128;   // K tile 8 KiB + V^T tile 8 KiB
 constexpr int QB = 2;                  // 32-row query blocks per wave
 constexpr int Q_TILE = 4 * QB * 32;    // query rows per block
 
+// PRE: q arrives pre-multiplied by scale*log2(e) (the UNet runtime folds it into the to_q weights, one
+// rounding); otherwise the scale is applied to the fp32 scores (one packed FMA per two scores).
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,8 +64,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 
   const char* zero = (const char*)hi3d_zero_page;
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[row li][d = ks*16 + hi*8 ..+7]
-  // of each of the wave's QB query blocks, pre-multiplied by scale*log2(e) so that a score is
-  // an exp2 argument as it comes out of the MFMA.
+  // of each of the wave's QB query blocks
   int qrow[QB]; bool qok[QB];
   bf16x8 qf[QB][4];
 #pragma unroll
@@ -72,12 +74,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     const char* qp = p.q + (((long)b * p.Sq + (qok[qb] ? qrow[qb] : 0)) * p.ldq + h * 64) * 2;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      union { bf16x8 v; unsigned int u[4]; } raw, sq;
-      raw.v = qok[qb] ? *(const bf16x8*)(qp + (ks * 16 + hi * 8) * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        sq.u[t] = pack_bf16x2(bf16_to_f32(raw.u[t] & 0xffff) * p.scale_log2, bf16_to_f32(raw.u[t] >> 16) * p.scale_log2);
-      qf[qb][ks] = sq.v;
+      qf[qb][ks] = qok[qb] ? *(const bf16x8*)(qp + (ks * 16 + hi * 8) * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
 
@@ -145,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   // -m_run in 16 equal registers per query block: the C operand of a tile's first score MFMA,
   // so the subtraction costs no VALU instruction (rewritten only by the exact pre-pass)
   f32x16 negm[QB];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -168,7 +166,19 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
         const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
-          sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? negm[qb] : sc[qb], 0, 0, 0);
+          sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? (PRE ? negm[qb] : zero16) : sc[qb], 0, 0, 0);
+      }
+      if (!PRE) {                                // scores -> log2 domain, relative to the reference point
+        const hi3d_f2 c2 = hi3d_f2{p.scale_log2, p.scale_log2};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const hi3d_f2 nm2 = hi3d_f2{-m_run[qb], -m_run[qb]};
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const hi3d_f2 t = hi3d_f2{sc[qb][r], sc[qb][r + 1]} * c2 + nm2;
+            sc[qb][r] = t[0]; sc[qb][r + 1] = t[1];
+          }
+        }
       }
       if (ragged) {
 #pragma unroll
@@ -437,7 +447,8 @@ extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void*
   p.scale_log2 = scale * 1.4426950408889634f;
   const long nblk = (long)p.nqt * H * B;
   if (nblk > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: grid too large");
-  hipLaunchKernelGGL(attn_d64_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  if (scale == 0.0f) hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_d64_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -130,11 +130,15 @@ def attention_d64(q, k, vt, B, H, S_q, S_kv, ldq, ldk, scale, out=None):
     return out
 
 
-def self_attention_fused_qkv(qkv, B, S, H, scale=None):
-    """qkv: [B*S, 3*H*64] bf16 (q | k | v column blocks). Returns [B*S, H*64]."""
+Q_PRESCALE = 64 ** -0.5 * 1.4426950408889634   # softmax scale * log2(e): folded into to_q by pack_qkv(..., q_scale=)
+
+
+def self_attention_fused_qkv(qkv, B, S, H, scale=None, q_prescaled=False):
+    """qkv: [B*S, 3*H*64] bf16 (q | k | v column blocks). Returns [B*S, H*64].
+    q_prescaled: the q block was produced by weights carrying Q_PRESCALE (scale is then ignored)."""
     C = H * 64
     assert qkv.shape == (B * S, 3 * C) and qkv.is_contiguous()
-    scale = 64 ** -0.5 if scale is None else scale
+    scale = 0.0 if q_prescaled else (64 ** -0.5 if scale is None else scale)
     vt = transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
     return attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
 

@@ -50,9 +50,13 @@ def pack_geglu(w, b):
     return _bf16(wp), bp.detach().to(torch.float32).contiguous()
 
 
-def pack_qkv(wq, wk, wv):
-    """to_q / to_k / to_v (bias-free, attention.py:272-274) -> one [3C, C] matrix."""
-    return _bf16(torch.cat([wq, wk, wv], dim=0))
+def pack_qkv(wq, wk, wv, q_scale=None):
+    """to_q / to_k / to_v (bias-free, attention.py:272-274) -> one [3C, C] matrix.
+    q_scale: factor folded into the to_q rows in fp32 before the (single) bf16 rounding -- the
+    spatial attention kernel then takes q as exp2-ready (softmax scale * log2 e)."""
+    if q_scale is not None:
+        wq = wq.detach().to(torch.float32) * q_scale
+    return _bf16(torch.cat([wq.to(torch.float32), wk.detach().to(torch.float32), wv.detach().to(torch.float32)], dim=0))
 
 
 def f32(t):

@@ -123,7 +123,10 @@ class UNetRuntime:
         def pack_attn_block(p, with_ff_in):
             for n in ("norm1", "norm3") + (("norm_in",) if with_ff_in else ()):
                 W[f"{p}.{n}.g"] = f32(f"{p}.{n}.weight"); W[f"{p}.{n}.b"] = f32(f"{p}.{n}.bias")
-            W[p + ".qkv.w"] = pack.pack_qkv(g(p + ".attn1.to_q.weight"), g(p + ".attn1.to_k.weight"), g(p + ".attn1.to_v.weight"))
+            # spatial blocks: softmax scale * log2(e) folded into to_q (the d64 kernel takes exp2-ready scores);
+            # the temporal block's kernel applies its scale itself
+            W[p + ".qkv.w"] = pack.pack_qkv(g(p + ".attn1.to_q.weight"), g(p + ".attn1.to_k.weight"), g(p + ".attn1.to_v.weight"),
+                                            q_scale=None if with_ff_in else ops.Q_PRESCALE)
             W[p + ".o.w"] = pack.pack_linear(g(p + ".attn1.to_out.0.weight")); W[p + ".o.b"] = f32(p + ".attn1.to_out.0.bias")
             # attn2 with a single context token: only to_v and to_out survive (norm2/to_q/to_k are dead)
             W[p + ".x.v"] = pack.pack_linear(g(p + ".attn2.to_v.weight"))
@@ -237,7 +240,7 @@ class UNetRuntime:
         # --- spatial block (attention.py:551-572)
         n = ops.layernorm(h, W[sp + ".norm1.g"], W[sp + ".norm1.b"], M, C)
         qkv = ops.gemm(n, W[sp + ".qkv.w"], M=M, N=3 * C, K=C)
-        a = ops.self_attention_fused_qkv(qkv, F_, S, Hh)
+        a = ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
         h = ops.gemm(a, W[sp + ".o.w"], M=M, N=C, K=C, bias=W[sp + ".o.b"], R1=h,
                      rowvec=cond[sp], rows_per_group=S)                     # + attn1 + attn2 (one token)
         n = ops.layernorm(h, W[sp + ".norm3.g"], W[sp + ".norm3.b"], M, C)

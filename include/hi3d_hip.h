@@ -116,7 +116,11 @@ int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
  *          base + (b*S + s)*ld + h*64      (heads interleaved "(h d)")
  *   vt   : V transposed per head, [B][H][64][S_pad] bf16 (see hi3d_transpose_v)
  *   out  : [B][S][ldo] with head h at column h*64
- * S_kv keys are attended by S_q queries (self-attention: equal).            */
+ * S_kv keys are attended by S_q queries (self-attention: equal).
+ * scale > 0: the softmax scale (1/sqrt(64) in the reference), applied to the fp32 scores.
+ * scale = 0: q already carries scale*log2(e) -- the UNet runtime folds that factor into the
+ *            to_q rows of the fused QKV weight before its single bf16 rounding -- and the
+ *            scores are used as exp2 arguments as they leave the matrix core.            */
 int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
                   int32_t B, int32_t H, int32_t S_q, int32_t S_kv,
                   int32_t ldq, int32_t ldk, int32_t ld_vt /* = S_pad */, int32_t ldo,

@@ -197,6 +197,56 @@ def test_attention_d64_online_softmax_rescale(dev):
     assert relerr(out, ref) < 2e-2
 
 
+def test_attention_d64_prescaled_q(dev):
+    """scale = 0 form: q arrives carrying scale*log2(e) (as the UNet runtime packs to_q); the
+    reference is a base-2 softmax of q'.k on the same bf16 operands."""
+    from hi3d_hip import ops
+    B, H, S = 2, 3, 300
+    C = H * 64
+    qkv = rnd((B * S, 3 * C), 41, 0.7)
+    qkv[:, :C] *= ops.Q_PRESCALE
+    qkv = bf(qkv)
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    p = torch.softmax((q @ k.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, C)
+    out = ops.self_attention_fused_qkv(qkv.to(dev), B, S, H, q_prescaled=True)
+    assert relerr(out, ref) < 2e-2
+
+
+@pytest.mark.parametrize("case", ["huge_logits", "all_very_negative", "late_outlier_ragged", "rising_max", "first_tile_outlier"])
+def test_attention_d64_reference_point_edge_cases(dev, case):
+    """The kernel's softmax does not track the true row maximum (it checks row sums and moves the
+    reference point only when they overflow): drive every branch of that with adversarial score
+    ranges and compare with an fp32 softmax.  Logit scale is q.k/8."""
+    from hi3d_hip import ops
+    B, H = 1, 2
+    S = {"late_outlier_ragged": 333}.get(case, 640)
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn((S, H, 64), generator=g) * 0.5
+    k = torch.randn((S, H, 64), generator=g) * 0.5
+    v = torch.randn((S, H, 64), generator=g)
+    if case == "huge_logits":                # |logit| up to several hundred: exp2 arguments far outside fp32 exp range
+        q, k = q * 12.0, k * 12.0
+    elif case == "all_very_negative":        # every score of a row << 0 relative to nothing: reference must follow down on tile 0
+        q = q.abs() + 1.0
+        k = -(k.abs() + 1.0) * 6.0
+    elif case == "late_outlier_ragged":      # dominant key inside the ragged last tile (keys 320..332)
+        q = q.abs()
+        k[330] = 8.0
+    elif case == "rising_max":               # the row maximum creeps up tile after tile (many small reference moves / none)
+        q = q.abs() + 0.5
+        k = k.abs() * torch.linspace(0.1, 4.0, S)[:, None, None]
+    elif case == "first_tile_outlier":       # huge first-tile maximum, everything later underflows relative to it
+        q = q.abs()
+        k[3] = 10.0
+    qkv = bf(torch.cat([q.reshape(S, H * 64), k.reshape(S, H * 64), v.reshape(S, H * 64)], dim=1))
+    qf, kf, vf = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(H * 64, dim=1)]
+    ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(S, H * 64)
+    out = ops.self_attention_fused_qkv(qkv.to(dev), B, S, H)
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out, ref) < 2e-2
+
+
 @pytest.mark.parametrize("B,T,S,H", [(2, 16, 50, 2), (1, 4, 33, 1), (1, 32, 20, 3), (2, 8, 16, 5), (1, 13, 9, 1)])
 def test_attention_temporal(dev, B, T, S, H):
     from hi3d_hip import ops
