@@ -91,6 +91,31 @@ def test_pack_geglu_and_conv_layouts():
     assert torch.equal(pt, t[..., 0, 0].permute(0, 2, 1).to(torch.bfloat16).float())
 
 
+def test_pack_qkv_folds_the_softmax_scale_with_one_rounding():
+    """to_q rows carry scale*log2(e) folded in fp32 before the bf16 rounding (the d64 attention kernel then
+    takes q as exp2-ready); to_k / to_v are untouched; the temporal block passes no scale."""
+    from hi3d_hip import ops
+    g = torch.Generator().manual_seed(3)
+    wq, wk, wv = (torch.randn((64, 64), generator=g) for _ in range(3))
+    plain = pack.pack_qkv(wq, wk, wv)
+    folded = pack.pack_qkv(wq, wk, wv, q_scale=ops.Q_PRESCALE)
+    assert abs(ops.Q_PRESCALE - 0.125 * 1.4426950408889634) < 1e-12
+    assert torch.equal(folded[64:], plain[64:])
+    assert torch.equal(folded[:64], (wq * ops.Q_PRESCALE).to(torch.bfloat16))          # one rounding, of the product
+    assert not torch.equal(folded[:64].float(), plain[:64].float() * ops.Q_PRESCALE)    # not a rescaled rounding
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    """No CPU path: an op handed host tensors raises instead of computing something else."""
+    from hi3d_hip import ops
+    x = torch.zeros((128, 320), dtype=torch.bfloat16)
+    w1, w2 = torch.zeros((2560, 320), dtype=torch.bfloat16), torch.zeros((320, 1280), dtype=torch.bfloat16)
+    with pytest.raises(ops._l.Hi3dError):
+        ops.ffn_geglu(x, w1, torch.zeros(2560), w2, torch.zeros(320), M=128, C=320)
+    with pytest.raises(ops._l.Hi3dError):
+        ops.gemm(x, w1, M=128, N=2560, K=320)
+
+
 def test_sampler_host_logic_matches_oracle_with_analytic_denoiser():
     """EulerEDMSampler + LinearPredictionGuider + Denoiser on CPU with a closed-form
     'network' (so no kernels are needed): same trajectory as the oracle's loop."""
