@@ -66,7 +66,7 @@ CIN_PAD = 64   # the 8 / 17 input channels are zero-padded to one 64-wide K chun
 
 
 class UNetRuntime:
-    def __init__(self, state_dict, cfg, device, prefix=""):
+    def __init__(self, state_dict, cfg, device, prefix="", cache_dir=None):
         self.cfg = dict(cfg)
         self.dev = torch.device(device)
         self.mc = cfg["model_channels"]
@@ -82,7 +82,19 @@ class UNetRuntime:
         self.fused_ffn = os.environ.get("HI3D_FUSED_FFN", "1") != "0"
         self._cond_cache = None
         self._pos_cache = {}
-        self._pack(state_dict, prefix)
+        # HI3D_PACK_CACHE=<dir>: keep / reuse the re-laid-out weights on disk (hi3d_hip/relayout_cache.py)
+        cache_dir = os.environ.get("HI3D_PACK_CACHE") if cache_dir is None else cache_dir
+        self.packed_from_cache = False
+        if cache_dir:
+            from . import relayout_cache as rc
+            fp = rc.fingerprint(state_dict, self.cfg, prefix)
+            path = rc.cache_path(cache_dir, fp)
+            self.packed_from_cache = rc.load_into(self, path, fp)
+            if not self.packed_from_cache:
+                self._pack(state_dict, prefix)
+                rc.save(self, path, fp)
+        else:
+            self._pack(state_dict, prefix)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, sd, P):

@@ -116,6 +116,37 @@ def test_ops_refuse_cpu_tensors_loudly():
         ops.gemm(x, w1, M=128, N=2560, K=320)
 
 
+def test_relayout_cache_roundtrip_and_invalidation(tmp_path):
+    """Packed-weight cache: a second runtime built from the same state_dict loads the file (identical
+    tensors and index tables, no packing); other weights / another config get another fingerprint."""
+    from hi3d_hip import relayout_cache as rc
+    from hi3d_hip.runtime_unet import UNetRuntime
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    fx = load("unet_tiny_s1")
+    m = VideoUNet(**fx["cfg"])
+    synth.fill_module_(m, 1, prefix=fx["key_prefix"])
+    sd = m.state_dict()
+    a = UNetRuntime(sd, m.cfg, "cpu", cache_dir=str(tmp_path))           # packs, writes
+    assert not a.packed_from_cache and len(list(tmp_path.iterdir())) == 1
+    b = UNetRuntime(sd, m.cfg, "cpu", cache_dir=str(tmp_path))           # loads
+    assert b.packed_from_cache
+    assert a.W.keys() == b.W.keys() and all(torch.equal(a.W[k], b.W[k]) and a.W[k].dtype == b.W[k].dtype for k in a.W)
+    assert torch.equal(a.mix, b.mix) and a.emb_slices == b.emb_slices and a.emb_total == b.emb_total
+    assert a.mix_index == b.mix_index and a.transformers == b.transformers
+    fp = rc.fingerprint(sd, m.cfg)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    k0 = next(k for k in sd2 if k.endswith("attn1.to_q.weight"))
+    sd2[k0].view(-1)[-1] += 1.0                                          # one changed element (the sampled last one)
+    assert rc.fingerprint(sd2, m.cfg) != fp
+    assert rc.fingerprint(sd, dict(m.cfg, max_ddpm_temb_period=123)) != fp
+    c = UNetRuntime(sd2, m.cfg, "cpu", cache_dir=str(tmp_path))          # different weights: packs again
+    assert not c.packed_from_cache and len(list(tmp_path.iterdir())) == 2
+    # a file from another packing scheme is ignored, not trusted
+    path = rc.cache_path(str(tmp_path), fp)
+    blob = torch.load(path, weights_only=False); blob["pack_version"] = -1; torch.save(blob, path)
+    assert not UNetRuntime(sd, m.cfg, "cpu", cache_dir=str(tmp_path)).packed_from_cache
+
+
 def test_sampler_host_logic_matches_oracle_with_analytic_denoiser():
     """EulerEDMSampler + LinearPredictionGuider + Denoiser on CPU with a closed-form
     'network' (so no kernels are needed): same trajectory as the oracle's loop."""
