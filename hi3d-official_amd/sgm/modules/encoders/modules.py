@@ -2,7 +2,9 @@
 
 The Hi3D conditioner runs ONCE per clip (OpenCLIP ViT-H image tower, MiDaS depth, VAE
 encoder of the conditioning frame ...) and is outside the denoising hot path this
-framework covers (SURVEY.md section 8, rank-3 "next").  What the hot path consumes is its
+framework covers (SURVEY.md section 8, rank-3 "next").  Built here: the scalar embedders and
+the conditioning-frame VAE embedder (it reuses the gfx950 VAE encoder); the CLIP and MiDaS
+towers are not.  What the hot path consumes is its
 OUTPUT: `c` / `uc` dicts with keys crossattn [B,1,1024], vector [B,adm], concat
 [T,Cc,h,w].  This container keeps the reference's combining rules for embedders that
 are available and reports the ones that are not, by name, when it is asked to run them.
@@ -33,6 +35,40 @@ class ConcatTimestepEmbedderND(AbstractEmbModel):
         b, dims = x.shape
         emb = ops.timestep_embedding(x.reshape(-1).float(), self.outdim)
         return emb.reshape(b, dims * self.outdim)
+
+
+class VideoPredictionEmbedderWithEncoder(AbstractEmbModel):
+    """The `concat` conditioning of stage 1: the conditioning frame through the first-stage VAE encoder
+    (mode of the posterior), scaled, repeated for the n_copies views (reference :951-1025).
+
+    Inference surface only: `sigma_sampler_config` / `sigma_cond_config` (training-time noise
+    augmentation inside the embedder) are refused.  The encoder is this framework's AutoencoderKL
+    mirror, i.e. the gfx950 VAE encoder runtime (hi3d_hip.runtime_vae.VAEEncoderRuntime); its
+    parameters keep the reference's names under `encoder.`."""
+
+    def __init__(self, n_cond_frames, n_copies, encoder_config, sigma_sampler_config=None, sigma_cond_config=None,
+                 is_ae=False, scale_factor=1.0, disable_encoder_autocast=False, en_and_decode_n_samples_a_time=None):
+        super().__init__()
+        if sigma_sampler_config is not None or sigma_cond_config is not None:
+            raise NotImplementedError("VideoPredictionEmbedderWithEncoder: sigma_sampler / sigma_cond are training-time options")
+        if not is_ae:
+            raise NotImplementedError("VideoPredictionEmbedderWithEncoder: only is_ae=True (encoder.encode) is wired")
+        self.n_cond_frames, self.n_copies = n_cond_frames, n_copies
+        self.encoder = instantiate_from_config(encoder_config)
+        self.is_ae, self.scale_factor = is_ae, scale_factor
+        self.disable_encoder_autocast = disable_encoder_autocast
+        self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+
+    def forward(self, vid):
+        """vid [(b n_cond_frames), 3, H, W] -> [(b n_copies), n_cond_frames*4, H/8, W/8]."""
+        n = vid.shape[0]
+        step = self.en_and_decode_n_samples_a_time or n
+        z = torch.cat([self.encoder.encode(vid[i:i + step]) for i in range(0, n, step)], dim=0)
+        z = z * self.scale_factor
+        bt, c, h, w = z.shape
+        b = bt // self.n_cond_frames
+        z = z.reshape(b, 1, self.n_cond_frames * c, h, w)                 # (b t) c h w -> b () (t c) h w
+        return z.expand(b, self.n_copies, self.n_cond_frames * c, h, w).reshape(b * self.n_copies, self.n_cond_frames * c, h, w)
 
 
 class _Unavailable(AbstractEmbModel):

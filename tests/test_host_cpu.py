@@ -201,6 +201,17 @@ def test_create_model_from_yaml_builds_engine():
     assert any(k.startswith("first_stage_model.decoder.conv_in.weight") for k in keys)
     assert m.num_samples == 16 and m.sampler.num_steps == 25 and m.sampler.guider.max_scale == 2.5
     assert abs(m.scale_factor - 0.18215) < 1e-9 and m.en_and_decode_n_samples_a_time == 16
+    # the conditioning-frame embedder is built on this framework's VAE encoder and keeps the reference's key names
+    from sgm.modules.encoders.modules import ConcatTimestepEmbedderND, VideoPredictionEmbedderWithEncoder, _Unavailable
+    emb = {e.input_key: e for e in m.conditioner.embedders}
+    assert isinstance(emb["cond_frames"], VideoPredictionEmbedderWithEncoder) and emb["cond_frames"].n_copies == 16
+    assert isinstance(emb["cond_aug"], ConcatTimestepEmbedderND)
+    assert isinstance(emb["cond_frames_without_noise"], _Unavailable)          # CLIP tower: reported, not built
+    i = list(m.conditioner.embedders).index(emb["cond_frames"])
+    assert f"conditioner.embedders.{i}.encoder.encoder.conv_in.weight" in keys
+    assert f"conditioner.embedders.{i}.encoder.quant_conv.weight" in keys
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        emb["cond_frames"](torch.zeros(1, 3, 64, 64))
 
 
 def test_autoencoding_engine_video_decoder_state_dict_matches_reference():

@@ -69,6 +69,31 @@ def test_vae_encode_matches_reference_golden(dev, name):
     assert torch.equal(z2, z)
 
 
+def test_cond_frame_embedder_matches_reference_encoder(dev):
+    """VideoPredictionEmbedderWithEncoder (encoders/modules.py:951-1025): VAE mode of the conditioning
+    frame, * scale_factor, `(b t) c h w -> b () (t c) h w`, repeated n_copies times."""
+    from hi3d_hip import synth
+    from sgm.modules.encoders.modules import VideoPredictionEmbedderWithEncoder
+    fx = torch.load(os.path.join(GOLD, "vae_enc_tiny.pt"), weights_only=False)
+    enc_cfg = {"target": "sgm.models.autoencoder.AutoencoderKLModeOnly",
+               "params": {"embed_dim": 4, "ddconfig": fx["ddconfig"], "lossconfig": {"target": "torch.nn.Identity"}}}
+    n = fx["x"].shape[0]
+    emb = VideoPredictionEmbedderWithEncoder(n_cond_frames=1, n_copies=3, encoder_config=enc_cfg, is_ae=True,
+                                             scale_factor=0.5, disable_encoder_autocast=True, en_and_decode_n_samples_a_time=1)
+    synth.fill_module_(emb.encoder, fx["weight_seed"], prefix=fx["key_prefix"])
+    out = emb.to(dev)(fx["x"].to(dev)).float().cpu()
+    mean = fx["moments"][:, :4] * 0.5
+    ref = mean[:, None].expand(n, 3, *mean.shape[1:]).reshape(n * 3, *mean.shape[1:])
+    assert out.shape == ref.shape
+    assert ((out - ref).abs().max() / ref.abs().max()).item() < 4e-2
+    two = VideoPredictionEmbedderWithEncoder(n_cond_frames=2, n_copies=2, encoder_config=enc_cfg, is_ae=True)
+    synth.fill_module_(two.encoder, fx["weight_seed"], prefix=fx["key_prefix"])
+    if n % 2 == 0:                                   # two conditioning frames stack on the channel axis
+        o2 = two.to(dev)(fx["x"].to(dev)).float().cpu()
+        m2 = fx["moments"][:, :4].reshape(n // 2, 1, 8, *mean.shape[2:]).expand(n // 2, 2, 8, *mean.shape[2:]).reshape(n, 8, *mean.shape[2:])
+        assert o2.shape == m2.shape and ((o2 - m2).abs().max() / m2.abs().max()).item() < 4e-2
+
+
 def test_conv3x3_bottom_right_padding(dev):
     import torch.nn.functional as F
     from hi3d_hip import ops
