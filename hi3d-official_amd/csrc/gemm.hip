@@ -31,6 +31,7 @@ struct GemmParams {
 };
 
 constexpr int BK = 64;
+constexpr int A_CONV3X3_UP2X = 3;   // internal: HI3D_A_CONV3X3 with up2x (own instantiation: the plain gather stays lean)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -39,10 +40,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // NS   : LDS ring stages.  NS = 2: loads of K-step k+1 fly during K-step k (vmcnt(0) per step).
 //        NS = 3: two K-steps in flight, counted vmcnt (the newest stage's LDS-DMA stays in
 //        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
-template <int WM, int NT, int NS, int AMODE, int EPI>
+template <int WM, int NT, int NS, int AMODE_, int EPI>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
+  constexpr bool UP2X = AMODE_ == A_CONV3X3_UP2X;
+  constexpr int AMODE = UP2X ? HI3D_A_CONV3X3 : AMODE_;
   constexpr int BM = WM * 64, BN = 32 * NT;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   } else if (AMODE == HI3D_A_CONV3X3) {
     const int f0 = m0 / (p.Hout * p.Wout);
     // origin shifted back by one row + one pixel so that every tap offset is >= 0
-    a_origin = p.A + ((long)f0 * p.Hin * p.Win - (p.up2x ? 0 : (p.Win + 1) * p.pad)) * p.Cin * 2;
+    a_origin = p.A + ((long)f0 * p.Hin * p.Win - (UP2X ? 0 : (p.Win + 1) * p.pad)) * p.Cin * 2;
   } else {
     a_origin = p.A + ((long)m0 - p.HW) * p.Cin * 2;      // one frame back: temporal tap 0
   }
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       const int f = mm / hw, rem = mm - f * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
       const int frel = f - m0 / hw;
-      if (p.up2x) {
+      if (UP2X) {
         a_p0[i] = oy; a_p1[i] = ox;
         a_voff[i] = ok ? (unsigned)((frel * p.Hin * p.Win) * p.Cin * 2 + chunk * 16) : INV;
       } else {
@@ -148,12 +151,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     char* sB = sA + A_BYTES;
     unsigned soff;                                 // scalar byte offset of this K chunk
     if (AMODE == HI3D_A_DENSE) soff = kt * (BK * 2);
-    else if (AMODE == HI3D_A_CONV3X3) soff = p.up2x ? c0 * 2 : (((tap / 3) * p.Win + (tap % 3)) * p.Cin + c0) * 2;
+    else if (AMODE == HI3D_A_CONV3X3) soff = UP2X ? c0 * 2 : (((tap / 3) * p.Win + (tap % 3)) * p.Cin + c0) * 2;
     else soff = (tap * p.HW * p.Cin + c0) * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       unsigned vo = a_voff[i];
-      if (AMODE == HI3D_A_CONV3X3 && p.up2x) {
+      if (AMODE == HI3D_A_CONV3X3 && UP2X) {
         const int iy = a_p0[i] + tap / 3 - 1, ix = a_p1[i] + tap % 3 - 1;   // on the virtual 2H x 2W grid
         const bool in = iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
         vo = (in && vo != INV) ? vo + (unsigned)(((iy >> 1) * p.Win + (ix >> 1)) * p.Cin * 2) : INV;
@@ -463,7 +466,8 @@ int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
   }
   switch (amode) {
     case HI3D_A_DENSE: return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
-    case HI3D_A_CONV3X3: return launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
+    case HI3D_A_CONV3X3: return p.up2x ? launch<WM, NT, NS, A_CONV3X3_UP2X, HI3D_EPI_AFFINE>(p, s)
+                                        : launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
     case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE>(p, s);
   }
   HI3D_FAIL(HI3D_EINVAL, "gemm: bad amode");
