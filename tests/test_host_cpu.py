@@ -147,6 +147,36 @@ def test_relayout_cache_roundtrip_and_invalidation(tmp_path):
     assert not UNetRuntime(sd, m.cfg, "cpu", cache_dir=str(tmp_path)).packed_from_cache
 
 
+def test_tensor2vid_and_video_export(tmp_path):
+    """Tail of the path (vtdm/util.py:13-50): frame order '(i f) h w c', truncation to uint8, and the
+    dependency-free AVI container (parsed back: header fields, frame count, pixel data)."""
+    import struct
+
+    import numpy as np
+    from vtdm.util import export_to_video, tensor2vid
+    g = torch.Generator().manual_seed(0)
+    vid = torch.rand((2, 3, 3, 5, 7), generator=g) * 2.4 - 1.2            # beyond [-1, 1]: clamped
+    frames = tensor2vid(vid.clone())
+    ref = ((vid * 0.5 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1).reshape(6, 5, 7, 3) * 255).numpy().astype("uint8")
+    assert len(frames) == 6 and all(f.shape == (5, 7, 3) and f.dtype == np.uint8 for f in frames)
+    assert np.array_equal(np.stack(frames), ref)
+    path = export_to_video(frames, str(tmp_path / "clip.mp4"), fps=8)
+    assert path.endswith(".avi") or path.endswith(".mp4")
+    if path.endswith(".avi"):
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+        i = raw.index(b"avih") + 8
+        usec, _, _, _, nfr, _, nstreams, _, w, h = struct.unpack("<10I", raw[i:i + 40])
+        assert (usec, nfr, nstreams, w, h) == (125000, 6, 1, 7, 5)
+        stride = (7 * 3 + 3) & ~3
+        k = raw.index(b"movi") + 4
+        for fr in frames:                                                 # '00db' <size> <bottom-up BGR rows, padded>
+            assert raw[k:k + 4] == b"00db" and struct.unpack("<I", raw[k + 4:k + 8])[0] == stride * 5
+            px = np.frombuffer(raw[k + 8:k + 8 + stride * 5], np.uint8).reshape(5, stride)[:, :21].reshape(5, 7, 3)
+            assert np.array_equal(px[::-1, :, ::-1], fr)
+            k += 8 + stride * 5
+
+
 def test_sampler_host_logic_matches_oracle_with_analytic_denoiser():
     """EulerEDMSampler + LinearPredictionGuider + Denoiser on CPU with a closed-form
     'network' (so no kernels are needed): same trajectory as the oracle's loop."""
