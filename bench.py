@@ -6,7 +6,12 @@ metric : denoise-steps/sec (one step = one EulerEDMSampler.sampler_step = CFG-do
 workload (N=1): stage-2 refiner, 16 views @ 1024x1024 (latent 128x128, in_channels 17),
          bf16 storage / fp32 accumulate, random-init weights of the full 1.52 B-parameter
          architecture (hi3d_hip.synth), synthetic conditioning, inputs resident in HBM.
-         `--config s1` selects stage-1 (16 views @ 512x512) instead.
+         `--config s1` selects stage-1 (16 views @ 512x512) instead; `--config vae` times the
+         first-stage decode of the clip (decode_first_stage, 16 frames @ 1024x1024) as its own line.
+timing : the K timed steps run the product path -- one HIP-graph replay per step
+         (hi3d_hip/fused_step.py).  Kernels inside a graph cannot be bracketed by events, so the
+         per-kernel HIP-event breakdown (`roofline`, `kernels_ms_per_step`) is taken over the K steps
+         that FOLLOW the timed region, same inputs and same kernels launched eagerly on the same stream.
 N > 1  : one process per GPU (torchrun); every rank denoises an independent orbit clip
          (replicas -- the unit that shards with no data-path collective, SURVEY 8e);
          value = steps of all ranks / max-over-ranks time; "scaling": "weak".
@@ -50,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["s1", "s2"], default="s2")
+    ap.add_argument("--config", choices=["s1", "s2", "vae"], default="s2")
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
@@ -78,6 +83,8 @@ def main():
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
+    if a.config == "vae":
+        return bench_vae(a, rank, world, dev, use_dist)
     stage = 1 if a.config == "s1" else 2
     T = a.views
     lat = 64 if stage == 1 else 128
@@ -121,19 +128,28 @@ def main():
         if use_dist:
             torch.distributed.barrier()
 
-    for i in range(a.warmup):
+    for i in range(max(a.warmup, 3)):           # >= 3: the third fused step captures the HIP graph
         x = step(i, x)
-    prof = None if a.no_profile else ops.Profiler()
     barrier(); torch.cuda.synchronize()
-    ops.PROFILER = prof
     t_start = time.perf_counter()
     for i in range(a.warmup, a.warmup + a.steps):
         x = step(i, x)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t_start
-    ops.PROFILER = None
     if not torch.isfinite(x).all():
         raise SystemExit("non-finite latents after the timed steps")
+    steppers = list(unet.runtime(dev).steppers.values())
+    graphed = bool(steppers) and steppers[0].graph is not None
+    # per-kernel breakdown: the same K steps again, launched eagerly with HIP events around every kernel
+    prof = None if a.no_profile else ops.Profiler()
+    if prof is not None:
+        ops.PROFILER = prof
+        t_p = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            x = step(i, x)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t_p) / a.steps * 1e3
+        ops.PROFILER = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -150,7 +166,8 @@ def main():
         "config": {"workload": f"Hi3D stage-{stage} VideoUNet sampler step, {T} views @ {lat * 8}x{lat * 8} "
                                f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
                                "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
-                   "global_batch": 2 * T * world, "parallelism": f"replicas x{world} (one clip per GPU)"},
+                   "global_batch": 2 * T * world, "parallelism": f"replicas x{world} (one clip per GPU)",
+                   "step_launch": "one HIP-graph replay per step" if graphed else "eager kernel launches"},
     }
     step_tf = STEP_TFLOP[stage] * (T / 16.0)
     out["step_roofline"] = {"bound": "mfma", "achieved": round(step_tf / (ms_per_step / 1e3), 1),
@@ -166,7 +183,8 @@ def main():
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
             log(f"[bench] {fam:16s} {d['ms'] / a.steps:9.3f} ms/step  {d['launches'] // a.steps:4d} launches/step  "
                 f"{tf:8.1f} TFLOP/s  {gbs:8.1f} GB/s(alg)")
-        log(f"[bench] kernels total {total_ms / a.steps:.2f} ms/step of {ms_per_step:.2f} ms/step wall")
+        log(f"[bench] kernels total {total_ms / a.steps:.2f} ms/step; wall {ms_per_step:.2f} ms/step "
+            f"({'graph replay' if graphed else 'eager'}), {eager_ms:.2f} ms/step eager with events")
         if a.shapes:
             for fam, d in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:40]:
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -191,7 +209,9 @@ def main():
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                            "launches_per_step": k_n // a.steps, "avg_launch_ms": round(k_ms / k_n, 4),
-                           "share_of_step": round(k_ms / a.steps / ms_per_step, 3)}
+                           "share_of_step": round(k_ms / a.steps / ms_per_step, 3),
+                           "timing": f"HIP events around every launch over the {a.steps} steps after the timed region "
+                                     "(the timed steps are graph replays)"}
         out["kernels_ms_per_step"] = {f: round(d["ms"] / a.steps, 3) for f, d in fams}
         if "attn_d64" in summ:
             d = summ["attn_d64"]
@@ -232,18 +252,87 @@ def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
     unet(x.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T, image_only_indicator=ioi.to(dev))
     torch.cuda.synchronize(); ops.PROFILER = None
     sample_flops = sum(d["flops"] for d in prof.summary().values())
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
+    threads = torch.get_num_threads()
+    times = []
     with torch.no_grad():
-        O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")
-    dt = time.perf_counter() - t0
+        O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")      # warm-up: first touch of 6 GB of weights
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")
+            times.append(time.perf_counter() - t0)
+            if sum(times) > 40.0:
+                break
+    dt = sorted(times)[len(times) // 2]          # median of the repeats
     cpu_tflops = sample_flops / dt / 1e12
     full = step_flops_exec if step_flops_exec else step_tf * 1e12
-    return {"value": round(cpu_tflops * 1e12 / full, 6), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 UNet forward, full width, T=8, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP in "
-                      f"{dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {cores} threads), extrapolated to the "
-                      f"{full / 1e12:.1f} TFLOP executed per full step",
-            "seconds": round(dt, 2)}
+    return {"value": round(cpu_tflops * 1e12 / full, 6), "unit": "steps/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"oracle fp32 UNet forward, full width, T=8, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP; median of "
+                      f"{len(times)} runs after one warm-up = {dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {threads} torch "
+                      f"threads, {os.cpu_count()} host CPUs), extrapolated to the {full / 1e12:.1f} TFLOP executed per full step",
+            "seconds": round(dt, 2), "runs_s": [round(t, 2) for t in times]}
+
+
+VAE_TFLOP_PER_FRAME = {512: 2.51, 1024: 10.47}     # decode_first_stage, BASELINE.md section 2
+
+
+def bench_vae(a, rank, world, dev, use_dist):
+    """decode_first_stage of one clip: `--views` frames at 1024x1024 (latent 128x128) through the full-width
+    AutoencoderKL decoder, en_and_decode_n_samples_a_time = 1 as configs/inference-v02.yaml ships.
+    A "step" is the decode of the whole clip; value = frames/s."""
+    from hi3d_hip import ops, synth
+    from sgm.models.autoencoder import AutoencoderKL
+    dd = dict(attn_type="vanilla-xformers", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    ae = AutoencoderKL(embed_dim=4, ddconfig=dd)
+    synth.fill_module_(ae, 1, prefix="first_stage_model.")
+    ae = ae.to(dev)
+    T, lat = a.views, 128
+    z = torch.randn(T, 4, lat, lat, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+
+    def clip():
+        return [ae.decode(z[i:i + 1]) for i in range(T)][-1]
+
+    for _ in range(max(1, a.warmup)):
+        out = clip()
+    if use_dist:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = clip()
+    torch.cuda.synchronize()
+    if use_dist:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out).all()
+    prof = ops.Profiler(); ops.PROFILER = prof
+    clip(); torch.cuda.synchronize(); ops.PROFILER = None
+    ms_frame = elapsed / a.steps / T * 1e3
+    tf = VAE_TFLOP_PER_FRAME[lat * 8]
+    res = {"metric": f"VAE decode frames/sec at {lat * 8}^2 (decode_first_stage)", "value": round(world * T * a.steps / elapsed, 3),
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+           "ms_per_frame": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic",
+           "config": {"workload": f"AutoencoderKL decoder (ch 128, mult 1-2-4-4), {T} frames @ {lat * 8}x{lat * 8}, one frame per call"},
+           "roofline": {"bound": "mfma", "achieved": round(tf / (ms_frame / 1e3), 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / (ms_frame / 1e3) / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "note": f"{tf} algorithmic TFLOP per frame / wall time per frame"}}
+    summ = prof.summary(by_shape=True)
+    for fam, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:30]:
+        tfk = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        log(f"[bench]   {fam:64s} {d['ms'] / T:8.3f} ms/frame {d['launches'] // T:3d}x {tfk:7.1f} TFLOP/s {gbs:7.0f} GB/s(alg)")
+    fams = prof.summary()
+    res["kernels_ms_per_frame"] = {f: round(d["ms"] / T, 3) for f, d in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

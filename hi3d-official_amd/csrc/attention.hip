@@ -2,8 +2,8 @@
 //
 // (1) attn_d64_kernel -- flash-style forward for head_dim 64 (the spatial
 //     self-attention of BasicTransformerBlock, sgm/modules/attention.py:332-336 /
-//     427-439; S up to 16384 tokens).  One block = 128 query rows of one (batch, head),
-//     4 waves x 32 rows.  K and V^T tiles of 64 keys are LDS-DMA'd (global_load_lds)
+//     427-439; S up to 16384 tokens).  One block = 256 query rows of one (batch, head),
+//     4 waves x 64 rows (two 32-row MFMA blocks per wave share every K / V^T fragment).  K and V^T tiles of 64 keys are LDS-DMA'd (global_load_lds)
 //     into a 2-stage ring with a source-side XOR swizzle (conflict-free ds_read_b128).
 //     Both matrix products run on v_mfma_f32_32x32x16_bf16 in "swapped" form,
 //         S^T[kv][q] = K . Q^T         O^T[d][q] = V^T . P^T

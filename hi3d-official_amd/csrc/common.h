@@ -84,6 +84,20 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // host side ---------------------------------------------------------------
 void hi3d_set_error(const char* msg);
+// hipFuncSetAttribute is a per-device property: a kernel that needs more than 64 KiB of dynamic LDS
+// raises its limit once per (kernel, device).  `done` is the caller's static per-kernel table.
+constexpr int HI3D_MAX_DEVICES = 64;
+inline int hi3d_raise_lds_limit(const void* fn, int bytes, bool (&done)[HI3D_MAX_DEVICES]) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { hi3d_set_error(hipGetErrorString(e)); return (int)e; }
+  const bool tracked = dev >= 0 && dev < HI3D_MAX_DEVICES;
+  if (tracked && done[dev]) return 0;              // benign race: idempotent
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { hi3d_set_error(hipGetErrorString(e)); return (int)e; }
+  if (tracked) done[dev] = true;
+  return 0;
+}
 #define HI3D_FAIL(code, msg) do { hi3d_set_error(msg); return (code); } while (0)
 #define HI3D_LAUNCH_CHECK()                                   \
   do {                                                        \

@@ -266,12 +266,8 @@ extern "C" int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, co
   p.R1 = (const unsigned short*)r1; p.R2 = (const unsigned short*)r2; p.a1 = a1; p.a2 = a2;
   p.out = (unsigned short*)out; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr1 = ldr1; p.ldr2 = ldr2;
   p.rpg = rows_per_group < 1 ? 1 : rows_per_group;
-  static bool attr_done = false;   // benign race: idempotent
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_geglu_c320_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS);
-    if (e != hipSuccess) { hi3d_set_error(hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static bool attr_done[HI3D_MAX_DEVICES] = {};
+  if (int rc = hi3d_raise_lds_limit((const void*)ffn_geglu_c320_kernel, FFN_LDS, attr_done)) return rc;
   hipLaunchKernelGGL(ffn_geglu_c320_kernel, dim3((M + FBM - 1) / FBM), dim3(FNW * 64), FFN_LDS, (hipStream_t)stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;

@@ -75,6 +75,53 @@ __global__ void sampler_step_kernel(float* __restrict__ x, const float* __restri
   }
 }
 
+// Per-step half of cfg_prepare for a graph-replayed sampler: only the 4 latent channels of both
+// CFG halves are rewritten (the conditioning channels of the token buffer are constant for a clip
+// and stay where hi3d_cfg_prepare put them); sigma is read from DEVICE memory so that one captured
+// launch serves every step.  Also emits c_noise = ln(sigma)/4 for the 2T rows of the batch.
+__global__ void cfg_update_x_kernel(const float* __restrict__ x, unsigned short* __restrict__ tok,
+                                    const float* __restrict__ sig, float* __restrict__ tvec,
+                                    int T, int HW, int Cp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * HW;
+  const float s = sig[0];
+  if (idx < 2 * T && tvec) tvec[idx] = 0.25f * logf(s);
+  if (idx >= total) return;
+  const float c_in = 1.0f / sqrtf(s * s + 1.0f);
+  const int p = (int)(idx % HW), t = (int)(idx / HW);
+  const float* xs = x + (long)t * 4 * HW + p;
+  const uint2 v = make_uint2(pack_bf16x2(xs[0] * c_in, xs[(long)HW] * c_in),
+                             pack_bf16x2(xs[2L * HW] * c_in, xs[3L * HW] * c_in));
+  *(uint2*)(tok + idx * Cp) = v;
+  *(uint2*)(tok + (total + idx) * Cp) = v;
+}
+
+// hi3d_sampler_step with sigma / sigma_next in device memory and an explicit output (may alias x)
+__global__ void sampler_step_dev_kernel(const float* __restrict__ x, float* __restrict__ xo,
+                                        const float* __restrict__ net, const float* __restrict__ scale,
+                                        const float* __restrict__ sig, int T, int HW, int ldn) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * HW;
+  if (idx >= total) return;
+  const float sg = sig[0], sn = sig[1];
+  const float c_skip = 1.0f / (sg * sg + 1.0f);
+  const float c_out = -sg / sqrtf(sg * sg + 1.0f);
+  const float dt_over_sigma = (sn - sg) / sg;
+  const int p = (int)(idx % HW), t = (int)(idx / HW);
+  const float* nu = net + idx * ldn;
+  const float* nc = net + (total + idx) * ldn;
+  const float s = scale[t];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const long o = ((long)t * 4 + c) * HW + p;
+    const float xv = x[o];
+    const float du = nu[c] * c_out + xv * c_skip;
+    const float dc = nc[c] * c_out + xv * c_skip;
+    const float d = du + s * (dc - du);
+    xo[o] = xv + dt_over_sigma * (xv - d);
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
                                     int C, int HW, int Cpad, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over N*HW*Cpad
@@ -262,6 +309,29 @@ extern "C" int hi3d_sampler_step(float* x, const float* net, const float* scale,
   const long total = (long)T * HW;
   hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
                      x, net, scale, T, HW, ldn, c_skip, c_out, dt_over_sigma);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_cfg_update_x(const float* x, void* tokens, const float* sigma_dev, float* c_noise_out,
+                                 int32_t T, int32_t HW, int32_t Cp, void* stream) {
+  if (!x || !tokens || !sigma_dev) HI3D_FAIL(HI3D_EINVAL, "cfg_update_x: null pointer");
+  if (T <= 0 || HW <= 0 || Cp < 4 || Cp % 4) HI3D_FAIL(HI3D_EINVAL, "cfg_update_x: bad size");
+  if ((uintptr_t)tokens & 7) HI3D_FAIL(HI3D_EALIGN, "cfg_update_x: tokens not 8-byte aligned");
+  const long total = (long)T * HW;
+  hipLaunchKernelGGL(cfg_update_x_kernel, dim3(grid_for(total > 2 * T ? total : 2 * T, 256, 1L << 30)), dim3(256), 0,
+                     (hipStream_t)stream, x, (unsigned short*)tokens, sigma_dev, c_noise_out, T, HW, Cp);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_sampler_step_dev(const float* x, float* x_out, const float* net, const float* scale,
+                                     const float* sigma_dev, int32_t T, int32_t HW, int32_t ldn, void* stream) {
+  if (!x || !x_out || !net || !scale || !sigma_dev) HI3D_FAIL(HI3D_EINVAL, "sampler_step_dev: null pointer");
+  if (T <= 0 || HW <= 0 || ldn < 4) HI3D_FAIL(HI3D_EINVAL, "sampler_step_dev: bad size");
+  const long total = (long)T * HW;
+  hipLaunchKernelGGL(sampler_step_dev_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, x_out, net, scale, sigma_dev, T, HW, ldn);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -52,9 +52,22 @@ PROFILER = None   # set to a Profiler() to record
 
 
 def _chk_dev(*ts):
+    """Every operand on ONE GPU, and that GPU is the current device: the launch goes to
+    torch.cuda.current_stream() of the current device, so a tensor of another GPU would be addressed from
+    the wrong stream (the runtimes wrap their passes in `torch.cuda.device(...)`)."""
+    idx = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _l.Hi3dError("hi3d ops need device tensors (got a CPU tensor); there is no CPU path")
+        if idx is None:
+            idx = t.device.index
+        elif t.device.index != idx:
+            raise _l.Hi3dError(f"hi3d op operands live on different GPUs (cuda:{idx} and cuda:{t.device.index})")
+    if idx is not None and idx != torch.cuda.current_device():
+        raise _l.Hi3dError(f"operands are on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "run under `torch.cuda.device(...)` / torch.cuda.set_device")
 
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
@@ -100,8 +113,18 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         nres = (R1 is not None) + (R2 is not None)
         epi = "geglu" if geglu else "+".join(x for x, on in (("b", bias is not None), ("rv", rowvec is not None),
                                                             ("R1", R1 is not None), ("R2", R2 is not None)) if on)
-        prof.end(fam, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out * (1 + nres)), t0,
-                 detail=f"M={M} N={N} K={K} {epi}")
+        # algorithmic bytes: every input element ONCE (the conv gathers read a pixel for up to 9 taps, but
+        # im2col never exists: M_in * Cin, not M * K), the weights, the output and the residual tiles
+        if conv3x3 is not None:
+            a_elems = (M // (d.Hout * d.Wout)) * d.Hin * d.Win * d.Cin
+            geo = f" {d.Hin}x{d.Win}->{d.Hout}x{d.Wout}"
+        elif convt3 is not None:
+            a_elems, geo = M * d.Cin, f" T={d.T}"
+        else:
+            a_elems, geo = M * K, ""
+        osz = 2.0 if out_fp32 else 1.0
+        prof.end(fam, 2.0 * M * N * K, 2.0 * (a_elems + N * K + M * n_out * (osz + nres)), t0,
+                 detail=f"M={M} N={N} K={K}{geo} {epi}")
     return out
 
 
@@ -222,11 +245,13 @@ def silu_to_bf16(x):
     return out
 
 
-def cfg_prepare(x, concat_uc, concat_c, Cp, sigma):
+def cfg_prepare(x, concat_uc, concat_c, Cp, sigma, out=None):
     """x: fp32 [T,4,H,W]; concat_*: fp32 [T,Cc,H,W] or None -> bf16 [2*T*HW, Cp]."""
+    _chk_dev(x, concat_uc, concat_c, out)
     T, _, H, W = x.shape
     Cc = 0 if concat_c is None else concat_c.shape[1]
-    out = torch.empty((2 * T * H * W, Cp), device=x.device, dtype=torch.bfloat16)
+    if out is None:
+        out = torch.empty((2 * T * H * W, Cp), device=x.device, dtype=torch.bfloat16)
     _l.check(_lib.hi3d_cfg_prepare(_p(x), _p(concat_uc), _p(concat_c), _p(out), T, H * W, Cc, Cp,
                                    float(sigma), _stream()), "hi3d_cfg_prepare")
     return out
@@ -237,6 +262,22 @@ def sampler_step(x, net, scale, ldn, sigma, sigma_next):
     _l.check(_lib.hi3d_sampler_step(_p(x), _p(net), _p(scale), T, H * W, ldn, float(sigma),
                                     float(sigma_next), _stream()), "hi3d_sampler_step")
     return x
+
+
+def cfg_update_x(x, tokens, sig, tvec, T, HW, Cp):
+    """Per-step part of cfg_prepare: tokens[u][t][p][0:4] = x * c_in(sig[0]) for both CFG halves, tvec[0:2T] =
+    ln(sig[0])/4; sigma is read on the device (graph-replayable)."""
+    _chk_dev(x, tokens, sig, tvec)
+    _l.check(_lib.hi3d_cfg_update_x(_p(x), _p(tokens), _p(sig), _p(tvec), T, HW, Cp, _stream()), "hi3d_cfg_update_x")
+    return tokens
+
+
+def sampler_step_dev(x, x_out, net, scale, sig, T, HW, ldn):
+    """x_out = Euler-EDM update of x from the CFG-doubled network output `net`; sig = device [sigma, sigma_next]."""
+    _chk_dev(x, x_out, net, scale, sig)
+    _l.check(_lib.hi3d_sampler_step_dev(_p(x), _p(x_out), _p(net), _p(scale), _p(sig), T, HW, ldn, _stream()),
+             "hi3d_sampler_step_dev")
+    return x_out
 
 
 def nchw_to_tokens(x, Cpad):

@@ -10,13 +10,20 @@ import math
 import torch
 
 from . import ops
+from .fused_step import StepRequest
 
 
 def _denoiser_fn(model, T, device):
-    extra = {"image_only_indicator": torch.zeros(2, T, device=device), "num_video_frames": T}
+    """The closure both reference pipelines build (pipeline_i2v_eval_v01.py:80-88).  image_only_indicator
+    has one row per clip of the batch the network sees: 2 for the CFG-doubled batch, 1 per rank under
+    hi3d_hip.parallel.SplitCFGGuider (each rank evaluates one half)."""
+    ioi = {n: torch.zeros(n, T, device=device) for n in (1, 2)}
 
     def denoiser(inp, sigma, c):
-        return model.denoiser(model.model, inp, sigma, c, **extra)
+        clips = 2 if isinstance(inp, StepRequest) else max(1, inp.shape[0] // T)
+        if clips not in ioi:
+            ioi[clips] = torch.zeros(clips, T, device=device)
+        return model.denoiser(model.model, inp, sigma, c, image_only_indicator=ioi[clips], num_video_frames=T)
     return denoiser
 
 

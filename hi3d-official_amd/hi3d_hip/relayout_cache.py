@@ -7,11 +7,14 @@ that is 6 GB moved to the device and converted on every start; the packed form i
 work.  This module stores it next to a fingerprint of what it was made from:
 
     fingerprint = sha256( PACK_VERSION, cfg, key prefix, every (key, shape, dtype) of the source
-                          state_dict, and a strided byte sample of every tensor )
+                          state_dict, and EVERY BYTE of every tensor )
 
 so that a different checkpoint, a changed config or a changed packing scheme (bump PACK_VERSION
-together with pack.py / runtime_unet.py) never loads a stale file.  The file is a plain
-`torch.save` of CPU tensors plus the runtime's small index tables.
+together with pack.py / runtime_unet.py) never loads a stale file -- including a checkpoint that differs
+from a cached one in a few rows only (partial fine-tune): hashing 6 GB costs seconds, once, and is far
+cheaper than the packing it saves.  The file holds CPU tensors plus the runtime's small index tables
+(lists / dicts of str and int) and is read back with `weights_only=True`: no pickled code is executed
+from the cache directory.
 """
 import hashlib
 import json
@@ -32,10 +35,8 @@ def fingerprint(state_dict, cfg, prefix=""):
         t = state_dict[k]
         h.update(f"|{k}:{tuple(t.shape)}:{t.dtype}".encode())
         flat = t.detach().reshape(-1)
-        if flat.numel():
-            step = max(1, flat.numel() // 64)                      # <= 64 samples per tensor, first and last included
-            sample = torch.cat([flat[::step][:64], flat[-1:]]).to("cpu", torch.float32)
-            h.update(sample.numpy().tobytes())
+        if flat.numel():                                           # the whole tensor, bit pattern as stored
+            h.update(flat.contiguous().cpu().view(torch.uint8).numpy().tobytes())
     return h.hexdigest()
 
 
@@ -49,8 +50,8 @@ def save(runtime, path, fp):
         "fingerprint": fp, "pack_version": PACK_VERSION,
         "W": {k: v.detach().to("cpu") for k, v in runtime.W.items()},
         "mix": runtime.mix.detach().to("cpu"),
-        "emb_slices": dict(runtime.emb_slices), "emb_total": int(runtime.emb_total),
-        "mix_index": dict(runtime.mix_index), "transformers": list(runtime.transformers),
+        "emb_slices": {k: list(v) for k, v in runtime.emb_slices.items()}, "emb_total": int(runtime.emb_total),
+        "mix_index": dict(runtime.mix_index), "transformers": [list(t) for t in runtime.transformers],
     }
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     tmp = f"{path}.tmp.{os.getpid()}"
@@ -64,7 +65,7 @@ def load_into(runtime, path, fp):
     if not os.path.exists(path):
         return False
     try:
-        blob = torch.load(path, map_location="cpu", weights_only=False)
+        blob = torch.load(path, map_location="cpu", weights_only=True)
     except Exception:
         return False
     if blob.get("pack_version") != PACK_VERSION or blob.get("fingerprint") != fp:
@@ -72,7 +73,7 @@ def load_into(runtime, path, fp):
     dev = runtime.dev
     runtime.W = {k: v.to(dev) for k, v in blob["W"].items()}
     runtime.mix = blob["mix"].to(dev)
-    runtime.emb_slices, runtime.emb_total = dict(blob["emb_slices"]), int(blob["emb_total"])
+    runtime.emb_slices, runtime.emb_total = {k: tuple(v) for k, v in blob["emb_slices"].items()}, int(blob["emb_total"])
     runtime.mix_index = dict(blob["mix_index"])
     runtime.transformers = [tuple(t) for t in blob["transformers"]]
     return True

@@ -80,8 +80,9 @@ class UNetRuntime:
         self.layout = unet_layout(cfg)
         # HI3D_FUSED_FFN=0 falls back to the two-GEMM feed-forward (A/B switch; both are HIP paths)
         self.fused_ffn = os.environ.get("HI3D_FUSED_FFN", "1") != "0"
-        self._cond_cache = None
+        self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
         self._pos_cache = {}
+        self.steppers = {}      # (T, H, W) -> hi3d_hip.fused_step.FusedStepper
         # HI3D_PACK_CACHE=<dir>: keep / reuse the re-laid-out weights on disk (hi3d_hip/relayout_cache.py)
         cache_dir = os.environ.get("HI3D_PACK_CACHE") if cache_dir is None else cache_dir
         self.packed_from_cache = False
@@ -187,28 +188,66 @@ class UNetRuntime:
         h = self._linear(x_bf16, k0, M, out_fp32=True)
         return self._linear(ops.silu_to_bf16(h), k2, M, out_fp32=True, rowvec=rowvec, rows_per_group=1)
 
-    def _conditioning(self, context, F_, T):
-        """Per-transformer cross-attention vectors; recomputed only when `context` changes."""
-        key = (context.data_ptr(), context._version, tuple(context.shape), F_, T)
-        if self._cond_cache is not None and self._cond_cache[0] == key:
-            return self._cond_cache[1]
-        if context.dim() != 3 or context.shape[1] != 1:
-            raise ops._l.Hi3dError(
-                f"context must be [B,1,{self.cfg['context_dim']}] (one CLIP image token, "
-                f"sgm/modules/encoders/modules.py:1041-1046); got {tuple(context.shape)}")
-        ctx = context[:, 0].to(self.dev, torch.float32)
-        if ctx.shape[0] != F_:
-            ctx = ctx.repeat_interleave(F_ // ctx.shape[0], dim=0)     # "fast implementation" repeat
-        ctx_s = ctx.to(torch.bfloat16).contiguous()                    # spatial: per frame  [F, ctx]
-        ctx_t = ctx[::T].to(torch.bfloat16).contiguous()               # temporal: clip's first frame [B, ctx]
-        out = {}
-        for p, C in self.transformers:
-            for blk, cx in ((p + ".transformer_blocks.0", ctx_s), (p + ".time_stack.0", ctx_t)):
-                M = cx.shape[0]
-                v = ops.gemm(cx, self.W[blk + ".x.v"], M=M, N=C, K=cx.shape[1])
-                out[blk] = ops.gemm(v, self.W[blk + ".x.o"], M=M, N=C, K=C, bias=self.W[blk + ".x.ob"], out_fp32=True)
-        self._cond_cache = (key, out)
-        return out
+    def clip_consts(self, context, y, image_only_indicator, F_, T):
+        """Everything the forward pass derives from the CONDITIONING alone (constant over the 25 steps of
+        a clip): the single-token cross-attention vectors, label_emb(y), the AlphaBlender factors.
+
+        They live in persistent buffers (one set per (F, T)) that are refreshed IN PLACE when an input
+        changes, so a captured HIP graph of the step keeps reading valid pointers.  "Changed" is decided
+        on the tensor OBJECT and its version counter while this cache holds a reference to it: the memory
+        cannot be recycled for another clip's conditioning behind our back (the round-1 cache keyed on
+        data_ptr could be, pipeline_i2v_eval_v01.py:106-118 loops over clips in one process).  A caller
+        that passes a fresh tensor every call simply pays the (cheap) refresh every call."""
+        st = self._clip.get((F_, T))
+        if st is None:
+            st = self._clip[(F_, T)] = {"ctx": None, "y": None, "ioi": None, "cond": {}, "lab": None}
+        dev, B = self.dev, F_ // T
+
+        def same(slot, t):
+            ref = st[slot]
+            return ref is not None and ref[0] is t and ref[1] == (None if t is None else t._version)
+
+        if not same("ctx", context):
+            if context.dim() != 3 or context.shape[1] != 1:
+                raise ops._l.Hi3dError(
+                    f"context must be [B,1,{self.cfg['context_dim']}] (one CLIP image token, "
+                    f"sgm/modules/encoders/modules.py:1041-1046); got {tuple(context.shape)}")
+            ctx = context[:, 0].to(dev, torch.float32)
+            if F_ % ctx.shape[0]:
+                raise ops._l.Hi3dError("context batch does not divide the frame batch")
+            if ctx.shape[0] != F_:
+                ctx = ctx.repeat_interleave(F_ // ctx.shape[0], dim=0)     # "fast implementation" repeat
+            ctx_s = ctx.to(torch.bfloat16).contiguous()                    # spatial: per frame  [F, ctx]
+            ctx_t = ctx[::T].to(torch.bfloat16).contiguous()               # temporal: clip's first frame [B, ctx]
+            for p, C in self.transformers:
+                for blk, cx in ((p + ".transformer_blocks.0", ctx_s), (p + ".time_stack.0", ctx_t)):
+                    M = cx.shape[0]
+                    v = ops.gemm(cx, self.W[blk + ".x.v"], M=M, N=C, K=cx.shape[1])
+                    st["cond"][blk] = ops.gemm(v, self.W[blk + ".x.o"], M=M, N=C, K=C, bias=self.W[blk + ".x.ob"],
+                                               out_fp32=True, out=st["cond"].get(blk))
+            st["ctx"] = (context, context._version)
+        if not same("y", y):
+            yb = y.to(dev, torch.float32)
+            if F_ % yb.shape[0]:
+                raise ops._l.Hi3dError("y batch does not divide the frame batch")
+            if yb.shape[0] != F_:
+                yb = yb.repeat_interleave(F_ // yb.shape[0], dim=0)
+            h = self._linear(yb.to(torch.bfloat16).contiguous(), "label_emb.0.0", F_, out_fp32=True)
+            st["lab"] = self._linear(ops.silu_to_bf16(h), "label_emb.0.2", F_, out_fp32=True, out=st["lab"])
+            st["y"] = (y, y._version)
+        if st["ioi"] is None or not same("ioi", image_only_indicator):
+            # AlphaBlender factors per frame (util.py:341-357)
+            if image_only_indicator is None:
+                ioi = torch.zeros((1, F_), device=dev, dtype=torch.bool)
+            else:
+                ioi = image_only_indicator.to(dev).reshape(1, F_) > 0
+            a_all = torch.where(ioi, torch.ones((), device=dev), torch.sigmoid(self.mix)[:, None]).contiguous()
+            if "a_all" in st:
+                st["a_all"].copy_(a_all); st["a1_all"].copy_(1.0 - a_all)
+            else:
+                st["a_all"], st["a1_all"] = a_all, (1.0 - a_all).contiguous()
+            st["ioi"] = (image_only_indicator, None if image_only_indicator is None else image_only_indicator._version)
+        return st
 
     def _pos_emb(self, p, C, B, T):
         key = (p, B, T)
@@ -284,25 +323,18 @@ class UNetRuntime:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward_tokens(self, x_tok, F_, H, Wd, timesteps, context, y, T, image_only_indicator):
-        """x_tok: bf16 [F*H*W, 64] (input channels zero-padded) -> fp32 [F*H*W, 4(out_channels)]."""
-        W, mc, dev = self.W, self.mc, self.dev
+    def forward_tokens(self, x_tok, F_, H, Wd, timesteps, st, T):
+        """x_tok: bf16 [F*H*W, 64] (input channels zero-padded) -> fp32 [F*H*W, 4(out_channels)].
+        timesteps: fp32 device [F]; st: clip_consts(...).  Issues HIP kernels only (graph-capturable)."""
+        W, mc = self.W, self.mc
         if F_ % T:
             raise ops._l.Hi3dError("batch is not a multiple of num_video_frames")
-        B = F_ // T
-        # ---- embeddings (video_model.py:456-469)
-        te = ops.timestep_embedding(timesteps.to(dev), mc, 10000.0, out_bf16=True)
-        t_emb = self._mlp_f32(te, "time_embed.0", "time_embed.2", F_)
-        yb = y.to(dev, torch.float32)
-        if yb.shape[0] != F_:
-            yb = yb.repeat_interleave(F_ // yb.shape[0], dim=0)
-        emb = self._mlp_f32(yb.to(torch.bfloat16).contiguous(), "label_emb.0.0", "label_emb.0.2", F_, rowvec=t_emb)
+        # ---- embeddings (video_model.py:456-469): emb = time_embed(t) + label_emb(y)
+        te = ops.timestep_embedding(timesteps, mc, 10000.0, out_bf16=True)
+        h = self._linear(te, "time_embed.0", F_, out_fp32=True)
+        emb = self._linear(ops.silu_to_bf16(h), "time_embed.2", F_, out_fp32=True, rowvec=st["lab"], rows_per_group=1)
         emb_all = self._linear(ops.silu_to_bf16(emb), "emb_all", F_, out_fp32=True)     # all 44 emb_layers at once
-        cond = self._conditioning(context, F_, T)
-        # ---- AlphaBlender factors per frame (util.py:341-357)
-        ioi = image_only_indicator.to(dev).reshape(1, F_) > 0
-        a_all = torch.where(ioi, torch.ones((), device=dev), torch.sigmoid(self.mix)[:, None]).contiguous()
-        a1_all = (1.0 - a_all).contiguous()
+        cond, a_all, a1_all = st["cond"], st["a_all"], st["a1_all"]
 
         blocks_in, middle, blocks_out = self.layout
         h, hs = x_tok, []
@@ -354,6 +386,11 @@ class UNetRuntime:
         F_, Cin, H, Wd = x.shape
         if Cin != self.cfg["in_channels"]:
             raise ops._l.Hi3dError(f"expected {self.cfg['in_channels']} input channels, got {Cin}")
-        tok = ops.nchw_to_tokens(x.to(self.dev), CIN_PAD)
-        out = self.forward_tokens(tok, F_, H, Wd, timesteps, context, y, T, image_only_indicator)
-        return ops.tokens_to_nchw(out, F_, self.cfg["out_channels"], H, Wd, self.cfg["out_channels"])
+        if F_ % T:
+            raise ops._l.Hi3dError("batch is not a multiple of num_video_frames")
+        with torch.cuda.device(self.dev):
+            st = self.clip_consts(context, y, image_only_indicator, F_, T)
+            tok = ops.nchw_to_tokens(x.to(self.dev), CIN_PAD)
+            ts = timesteps.to(self.dev, torch.float32).contiguous()
+            out = self.forward_tokens(tok, F_, H, Wd, ts, st, T)
+            return ops.tokens_to_nchw(out, F_, self.cfg["out_channels"], H, Wd, self.cfg["out_channels"])

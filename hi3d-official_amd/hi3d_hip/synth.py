@@ -88,3 +88,17 @@ def synth_conditioning(T: int, h: int, w: int, stage: int = 1, seed: int = 0, co
           "concat": torch.zeros_like(concat)}
     x = torch.randn((T, 4, h, w), generator=g)
     return x, c, uc
+
+
+def synth_unet_inputs(cfg, T: int, hw: int, seed: int):
+    """Seeded VideoUNet.forward arguments for a CFG-doubled batch of 2 clips x T frames (the inputs
+    of the `unet_*` golden fixtures; CPU generator, so identical wherever it is drawn)."""
+    g = torch.Generator().manual_seed(seed)
+    B = 2 * T
+    return dict(
+        x=torch.randn((B, cfg["in_channels"], hw, hw), generator=g),
+        timesteps=0.25 * torch.log(torch.rand((B,), generator=g) * 50 + 0.01),
+        context=torch.randn((2, 1, cfg["context_dim"]), generator=g),
+        y=torch.randn((2, cfg["adm_in_channels"]), generator=g),
+        image_only_indicator=torch.zeros(2, T),
+    )

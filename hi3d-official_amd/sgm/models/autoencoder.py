@@ -5,7 +5,7 @@ Holds the reference's parameter names (`encoder.*`, `decoder.*`, `quant_conv`,
 `encode` runs VAEEncoderRuntime (stage-2 pre-loop: once per frame, once per clip)."""
 import torch
 
-from ..util import ParamTree
+from ..util import ParamTree, params_key
 
 
 def _shape_helpers(S):
@@ -113,8 +113,7 @@ class AutoencoderKL(ParamTree):
 
     def runtime(self, device):
         from hi3d_hip.runtime_vae import VAEDecoderRuntime
-        p0 = next(self.parameters())
-        key = (torch.device(device), p0.data_ptr(), p0._version, p0.dtype)
+        key = params_key(self, device)
         if self._runtime is None or self._runtime_key != key:
             self._runtime = VAEDecoderRuntime(self.state_dict(), self.ddconfig, device)
             self._runtime_key = key
@@ -131,8 +130,7 @@ class AutoencoderKL(ParamTree):
 
     def encoder_runtime(self, device):
         from hi3d_hip.runtime_vae import VAEEncoderRuntime
-        p0 = next(self.parameters())
-        key = (torch.device(device), p0.data_ptr(), p0._version, p0.dtype)
+        key = params_key(self, device)
         if getattr(self, "_enc_runtime", None) is None or self._enc_key != key:
             self._enc_runtime = VAEEncoderRuntime(self.state_dict(), self.ddconfig, device)
             self._enc_key = key
@@ -186,8 +184,7 @@ class AutoencodingEngine(torch.nn.Module):
         return getattr(self.decoder, "temporal", False)
 
     def _key(self, device):
-        p0 = next(self.parameters())
-        return (torch.device(device), p0.data_ptr(), p0._version, p0.dtype)
+        return params_key(self, device)
 
     @torch.no_grad()
     def decode(self, z, **kwargs):

@@ -16,6 +16,13 @@ class Denoiser(nn.Module):
         return c_noise
 
     def forward(self, network, input, sigma, cond, **additional_model_inputs):
+        from hi3d_hip import fused_step
+        if isinstance(input, fused_step.StepRequest):
+            # EDMSampler.step_call asks for the whole step as one kernel sequence / graph replay
+            done = fused_step.serve(self, network, input, additional_model_inputs)
+            if done is not None:
+                return done
+            input, sigma, cond = input.materialize()       # not the Hi3D structure: generic math below
         sigma = self.possibly_quantize_sigma(sigma)
         flat_shape = sigma.shape
         c_skip, c_out, c_in, c_noise = self.scaling(append_dims(sigma, input.ndim))

@@ -22,6 +22,7 @@ class LinearPredictionGuider:
             additional_cond_keys = [additional_cond_keys]
         self.additional_cond_keys = list(additional_cond_keys)
         self._scale_dev = {}
+        self._merged = {}
 
     def _scale_on(self, device):
         if device not in self._scale_dev:
@@ -36,12 +37,22 @@ class LinearPredictionGuider:
         x_u, x_c = x_u.reshape((b, T) + x_u.shape[1:]), x_c.reshape((b, T) + x_c.shape[1:])
         return (x_u + scale * (x_c - x_u)).reshape((b * T,) + x_u.shape[2:])
 
+    def _cat(self, k, u, v):
+        """cat(uc[k], c[k]) is constant over the steps of a clip: built once and reused while the two
+        source tensors are the same objects at the same version (the cache holds them, so their memory
+        cannot be handed to another clip's conditioning).  Downstream caches (UNetRuntime.clip_consts)
+        key on the identity of what this returns."""
+        m = self._merged.get(k)
+        if m is None or m[0] is not u or m[1] != u._version or m[2] is not v or m[3] != v._version:
+            m = self._merged[k] = (u, u._version, v, v._version, torch.cat((u, v), 0))
+        return m[4]
+
     def prepare_inputs(self, x, s, c, uc):
         doubled = ["vector", "crossattn", "concat"] + self.additional_cond_keys
         c_out = {}
         for k in c:
             if k in doubled:
-                c_out[k] = torch.cat((uc[k], c[k]), 0)
+                c_out[k] = self._cat(k, uc[k], c[k])
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]

@@ -12,7 +12,7 @@ from typing import List, Optional, Union
 import torch
 import torch.nn as nn
 
-from ...util import ParamTree
+from ...util import ParamTree, params_key
 
 
 def unet_param_shapes(cfg):
@@ -171,7 +171,7 @@ class VideoUNet(ParamTree):
         if device.type != "cuda":
             raise RuntimeError("VideoUNet runs on the MI355X only: move the model or its inputs to cuda "
                                "(no CPU path exists in this framework)")
-        key = (device, p0.data_ptr(), p0._version, p0.dtype)
+        key = params_key(self, device)
         if self._runtime is None or self._runtime_key != key:
             self._runtime = UNetRuntime(self.state_dict(), self.cfg, device)
             self._runtime_key = key

@@ -97,3 +97,12 @@ def _default_init(key, t):
             t.fill_(1.0)
         else:
             t.zero_()
+
+
+def params_key(module, device):
+    """Identity of a module's current parameter VALUES for the packed-runtime caches: device, dtype,
+    storage of the first parameter, and the sum of every parameter's version counter -- so an in-place
+    update of ANY tensor (load_state_dict(strict=False) of a partial checkpoint, merged LoRA / EMA
+    weights), a dtype cast or a move re-packs, not only a change of the first tensor."""
+    ps = list(module.parameters())
+    return (torch.device(device), ps[0].dtype, ps[0].data_ptr(), len(ps), sum(p._version for p in ps))

@@ -210,6 +210,22 @@ int hi3d_sampler_step(float* x, const float* net, const float* scale, int32_t T,
                       int32_t HW, int32_t ldn, float sigma, float sigma_next,
                       void* stream);
 
+/* Graph-replayable forms of the two calls above: sigma (and sigma_next) are read from DEVICE
+ * memory, so one captured launch serves all 25 steps of sampling.py:109-147.
+ *
+ * hi3d_cfg_update_x rewrites only the 4 latent channels of both CFG halves of the token buffer
+ *   tokens[u][t][p][0:4] = x[t][0:4][p] * c_in(sigma_dev[0])        (denoiser.py:36-37)
+ * -- the conditioning channels hi3d_cfg_prepare wrote (`c["concat"]`, constant over the steps of a
+ * clip: guiders.py:88-99 / wrappers.py:26 re-concatenate them every step) stay in place -- and writes
+ * c_noise_out[0 .. 2T) = ln(sigma)/4 (denoiser_scaling.py:58) unless it is NULL.
+ *
+ * hi3d_sampler_step_dev is hi3d_sampler_step with sigma_dev = {sigma, sigma_next} and an explicit
+ * output tensor (x_out may alias x).                                                      */
+int hi3d_cfg_update_x(const float* x, void* tokens, const float* sigma_dev, float* c_noise_out,
+                      int32_t T, int32_t HW, int32_t Cp, void* stream);
+int hi3d_sampler_step_dev(const float* x, float* x_out, const float* net, const float* scale,
+                          const float* sigma_dev, int32_t T, int32_t HW, int32_t ldn, void* stream);
+
 /* NCHW fp32 <-> channels-last bf16 converters used at the module boundary
  * (VideoUNet.forward keeps the reference's NCHW signature).                  */
 int hi3d_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t HW,

@@ -58,18 +58,13 @@ def build_unet(cfg, seed):
 
 
 def unet_inputs(cfg, T, hw, seed):
-    g = torch.Generator().manual_seed(seed)
-    B = 2 * T
-    return dict(
-        x=torch.randn((B, cfg["in_channels"], hw, hw), generator=g),
-        timesteps=0.25 * torch.log(torch.rand((B,), generator=g) * 50 + 0.01),
-        context=torch.randn((2, 1, cfg["context_dim"]), generator=g),
-        y=torch.randn((2, cfg["adm_in_channels"]), generator=g),
-        image_only_indicator=torch.zeros(2, T),
-    )
+    return synth.synth_unet_inputs(cfg, T, hw, seed)
 
 
-def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None):
+def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None, compact=False):
+    """compact: the inputs are NOT stored (they are re-drawn from `input_seed` by
+    synth.synth_unet_inputs, pinned by `input_probe`) and the output is stored in fp16 -- for the
+    full-size stage-2 forward, whose fp32 input alone is 36 MB."""
     t0 = time.time()
     m = build_unet(cfg, wseed)
     inp = unet_inputs(cfg, T, hw, iseed)
@@ -82,8 +77,15 @@ def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None):
     fx = dict(kind="unet", cfg=cfg, T=T, weight_seed=wseed, key_prefix=UNET_PREFIX, inputs=inp, output=out,
               n_tensors=len(sd), shapes_sha256=shapes_digest(sd), shapes={k: tuple(v.shape) for k, v in sd.items()},
               probe={k: sd[k].flatten()[:4].clone() for k in list(sd)[:3]})
+    if compact:
+        x = inp["x"]
+        fx["inputs"] = None
+        fx["input_seed"], fx["hw"] = iseed, hw
+        fx["input_probe"] = dict(head=x.flatten()[:16].clone(), sum=float(x.double().sum()), abs_sum=float(x.double().abs().sum()))
+        fx["output_absmax"], fx["output_std"] = float(out.abs().max()), float(out.std())
+        fx["output"] = out.to(torch.float16)
     torch.save(fx, os.path.join(GOLD, name + ".pt"))
-    print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} std {out.std():.4f}  ({time.time() - t0:.1f}s)")
+    print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} std {out.std():.4f}  ({time.time() - t0:.1f}s)", flush=True)
 
 
 def gen_sampler(name, cfg, T, hw, steps, max_scale, stage, wseed=1, iseed=0):
@@ -123,7 +125,8 @@ def gen_sampler(name, cfg, T, hw, steps, max_scale, stage, wseed=1, iseed=0):
     print(f"{name}: final absmax {x.abs().max():.4f} std {x.std():.4f} ({time.time() - t0:.1f}s)")
 
 
-def gen_vae(name, ch, n, hw, wseed=1, iseed=0):
+def gen_vae(name, ch, n, hw, wseed=1, iseed=0, compact=False):
+    """compact: z is re-drawn from `input_seed` by the test (pinned by `z_head`), the image is stored in fp16."""
     t0 = time.time()
     AE = ref_import.ref("sgm.models.autoencoder.AutoencoderKL")
     dd = vae_ddconfig(ch)
@@ -136,6 +139,9 @@ def gen_vae(name, ch, n, hw, wseed=1, iseed=0):
     sd = ae.state_dict()
     fx = dict(kind="vae_decode", ddconfig=dd, weight_seed=wseed, key_prefix=VAE_PREFIX, z=z, output=out,
               shapes={k: tuple(v.shape) for k, v in sd.items()}, shapes_sha256=shapes_digest(sd))
+    if compact:
+        fx.update(z=None, input_seed=iseed, z_shape=tuple(z.shape), z_head=z.flatten()[:16].clone(),
+                  output=out.to(torch.float16), output_absmax=float(out.abs().max()))
     torch.save(fx, os.path.join(GOLD, name + ".pt"))
     print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
@@ -267,6 +273,15 @@ def main():
     }
     if a.full:
         jobs["unet_s1_full"] = lambda: gen_unet("unet_s1_full", unet_cfg(1), T=16, hw=64, iseed=7)
+        # the benchmarked shape (BASELINE config[2]): B = 2x16 frames, latent 128x128, 17 input channels
+        # (~15-25 min on 8 cores, ~45 GB peak)
+        # bf16 error accumulation over the whole 25-step schedule at full width (~4 min)
+        jobs["sampler_s1_w320_25step"] = lambda: gen_sampler("sampler_s1_w320_25step", unet_cfg(1), T=4, hw=16, steps=25,
+                                                             max_scale=2.5, stage=1, iseed=9)
+        # decode_first_stage of one frame at the two shipped resolutions, full-width decoder
+        jobs["vae_full_512"] = lambda: gen_vae("vae_full_512", 128, 1, 64, iseed=5, compact=True)
+        jobs["vae_full_1024"] = lambda: gen_vae("vae_full_1024", 128, 1, 128, iseed=6, compact=True)
+        jobs["unet_s2_full"] = lambda: gen_unet("unet_s2_full", unet_cfg(2), T=16, hw=128, iseed=8, compact=True)
     for k, fn in jobs.items():
         if a.only is None or a.only == k:
             fn()

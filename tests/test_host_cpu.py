@@ -136,8 +136,12 @@ def test_relayout_cache_roundtrip_and_invalidation(tmp_path):
     fp = rc.fingerprint(sd, m.cfg)
     sd2 = {k: v.clone() for k, v in sd.items()}
     k0 = next(k for k in sd2 if k.endswith("attn1.to_q.weight"))
-    sd2[k0].view(-1)[-1] += 1.0                                          # one changed element (the sampled last one)
+    sd2[k0].view(-1)[-1] += 1.0                                          # one changed element
     assert rc.fingerprint(sd2, m.cfg) != fp
+    sd3 = {k: v.clone() for k, v in sd.items()}
+    n = sd3[k0].numel()
+    sd3[k0].view(-1)[n // 2 + 7] += 1e-3                                 # one element in the MIDDLE of a tensor (round 1's
+    assert rc.fingerprint(sd3, m.cfg) != fp                              #   65-sample fingerprint collided here)
     assert rc.fingerprint(sd, dict(m.cfg, max_ddpm_temb_period=123)) != fp
     c = UNetRuntime(sd2, m.cfg, "cpu", cache_dir=str(tmp_path))          # different weights: packs again
     assert not c.packed_from_cache and len(list(tmp_path.iterdir())) == 2
@@ -258,3 +262,58 @@ def test_autoencoding_engine_video_decoder_state_dict_matches_reference():
     from sgm.modules.autoencoding.temporal_ae import VideoDecoder
     with pytest.raises(NotImplementedError, match="time_mode"):
         VideoDecoder(**dd, video_kernel_size=[3, 1, 1], time_mode="all")
+
+
+def test_runtime_repack_key_sees_any_parameter_update():
+    """The packed runtime is rebuilt when ANY parameter changes in place (partial checkpoint, merged
+    LoRA / EMA), not only the first tensor."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from sgm.util import params_key
+    fx = load("unet_tiny_s1")
+    m = VideoUNet(**fx["cfg"])
+    k0 = params_key(m, "cpu")
+    assert params_key(m, "cpu") == k0
+    last = list(m.parameters())[-1]
+    with torch.no_grad():
+        last.add_(1.0)
+    assert params_key(m, "cpu") != k0
+    k1 = params_key(m, "cpu")
+    some = dict(list(m.state_dict().items())[100:103])
+    m.load_state_dict({k: v + 1 for k, v in some.items()}, strict=False)
+    assert params_key(m, "cpu") != k1
+
+
+@pytest.mark.parametrize("fmt", ["ckpt", "pt", "safetensors"])
+def test_init_from_ckpt_three_formats(tmp_path, fmt):
+    """VideoLDM.init_from_ckpt (vtdm/vtdm_gen_v01.py:30-56): Lightning .ckpt {'state_dict': ...},
+    DeepSpeed .pt {'module': {'module.<key>': ...}} (how first_stage.pt / second_stage.pt ship), safetensors."""
+    import yaml
+    from vtdm.model import create_model
+    y = yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml")))
+    y["model"]["params"]["network_config"]["params"]["model_channels"] = 64
+    y["model"]["params"]["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
+    cfgp = tmp_path / "cfg.yaml"
+    yaml.safe_dump(y, open(cfgp, "w"))
+    m = create_model(str(cfgp))
+    keys = [k for k in m.state_dict() if k.startswith("model.diffusion_model.") or k.startswith("first_stage_model.")]
+    sd = {k: synth.synth_tensor(k, m.state_dict()[k].shape, seed=5) for k in keys}
+    path = str(tmp_path / f"w.{fmt}")
+    if fmt == "ckpt":
+        torch.save({"state_dict": sd, "global_step": 7}, path)
+    elif fmt == "pt":
+        torch.save({"module": {"module." + k: v for k, v in sd.items()}, "dp_world_size": 8}, path)
+    else:
+        from safetensors.torch import save_file
+        save_file(sd, path)
+    before = params_key_of(m)
+    m.init_from_ckpt(path)
+    got = m.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in keys)
+    assert params_key_of(m) != before                 # the UNet runtime will re-pack
+    with pytest.raises(NotImplementedError):
+        m.init_from_ckpt(str(tmp_path / "w.bin"))
+
+
+def params_key_of(m):
+    from sgm.util import params_key
+    return params_key(m.model.diffusion_model, "cpu")

@@ -6,6 +6,7 @@ the oracle is fp32.  Tolerances (stated, north_star "within a stated fp toleranc
   UNet output  : max-abs error <= 4e-2 x max-abs reference, cosine >= 0.9995
   sampler      : per-step latents cosine >= 0.999, max-abs rel <= 6e-2
 """
+import math
 import os
 
 import pytest
@@ -160,3 +161,94 @@ def test_unet_32_views_vs_oracle(dev):
     rel, cos = stats(out, ref)
     print(f"32 views: rel {rel:.4f} cos {cos:.6f}")
     assert rel < 4e-2 and cos > 0.9995
+
+
+def _sampler_stack(fx, dev):
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    T = fx["T"]
+    unet = build_unet(fx, dev)
+    model = OpenAIWrapper(unet)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = EulerEDMSampler(
+        num_steps=fx["steps"], device=dev,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": fx["max_scale"], "min_scale": 1.0}})
+    extra = dict(image_only_indicator=torch.zeros(2, T, device=dev), num_video_frames=T)
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+    return unet, sampler, denoiser
+
+
+def test_two_clips_through_one_model_do_not_share_conditioning(dev):
+    """pipeline_i2v_eval_v01.py:106-118 runs clip after clip through one model.  Round 1 cached the
+    cross-attention vectors on context.data_ptr(): a second clip whose context landed on the recycled
+    address silently reused the first clip's.  Clip 2 (different crossattn / vector / concat, the first
+    clip's tensors freed) must match the ORACLE on its own conditioning, on both step paths."""
+    from hi3d_hip import synth
+    from oracle import hi3d_oracle as O
+    fx = load("sampler_tiny_s1")
+    T, cfg = fx["T"], fx["cfg"]
+    unet, sampler, denoiser = _sampler_stack(fx, dev)
+    sd = {fx["key_prefix"] + k: v.float().cpu() for k, v in unet.state_dict().items()}
+    h = fx["x0"].shape[-1]
+
+    def oracle_step0(x0, c, uc, sigmas):
+        """first Euler step on the CPU oracle (denoiser.py:23-39, guiders.py:78-99, sampling.py:93-107)"""
+        s0, s1 = float(sigmas[0]), float(sigmas[1])
+        x = x0 * math.sqrt(1 + s0 * s0)
+        c_skip, c_out, c_in = 1 / (s0 * s0 + 1), -s0 / math.sqrt(s0 * s0 + 1), 1 / math.sqrt(s0 * s0 + 1)
+        xin = torch.cat([torch.cat([x, x]) * c_in, torch.cat([uc["concat"], c["concat"]])], 1)
+        net = O.video_unet(sd, cfg, xin, torch.full((2 * T,), 0.25 * math.log(s0)), torch.cat([uc["crossattn"], c["crossattn"]]),
+                           torch.cat([uc["vector"], c["vector"]]), T, torch.zeros(2, T), prefix=fx["key_prefix"])
+        den = net * c_out + torch.cat([x, x]) * c_skip
+        du, dc = den.chunk(2)
+        scale = torch.linspace(1.0, fx["max_scale"], T)[:, None, None, None]
+        d = du + scale * (dc - du)
+        return x + (s1 - s0) * (x - d) / s0
+
+    import math
+    for fused in ("1", "0"):
+        os.environ["HI3D_FUSED_STEP"] = fused
+        try:
+            for clip_seed in (100, 200, 300):
+                x0, c, uc = synth.synth_conditioning(T, h, h, stage=1, seed=clip_seed, adm_in=cfg["adm_in_channels"])
+                cd = {k: v.to(dev) for k, v in c.items()}
+                ucd = {k: v.to(dev) for k, v in uc.items()}
+                x, s_in, sigmas, num_sigmas, cond, ucond = sampler.prepare_sampling_loop(x0.clone().to(dev), cd, ucd)
+                got = sampler.step_call(denoiser, x, 0, s_in, sigmas, num_sigmas, cond, ucond)
+                ref = oracle_step0(x0, c, uc, sigmas.cpu())
+                rel, cos = stats(got, ref)
+                print(f"fused={fused} clip {clip_seed}: rel {rel:.4f} cos {cos:.6f}")
+                assert rel < 6e-2 and cos > 0.999
+                del cd, ucd, cond, ucond, x, got            # free the clip's tensors: the allocator may recycle them
+        finally:
+            os.environ.pop("HI3D_FUSED_STEP", None)
+
+
+def test_fused_graph_step_equals_generic_step(dev):
+    """The one-graph-replay step (hi3d_hip/fused_step.py) against the generic per-op path
+    (HI3D_FUSED_STEP=0: guider cat -> Denoiser math -> OpenAIWrapper cat -> VideoUNet -> guider -> Euler)
+    on the same model: same kernels inside the UNet, so the two agree to fp32 rounding of the
+    elementwise tail; and the fused path must really have been taken and captured."""
+    fx = load("sampler_tiny_s2")
+    unet, sampler, denoiser = _sampler_stack(fx, dev)
+    c = {k: v.to(dev) for k, v in fx["c"].items()}
+    uc = {k: v.to(dev) for k, v in fx["uc"].items()}
+    outs = {}
+    for fused in ("1", "0"):
+        os.environ["HI3D_FUSED_STEP"] = fused
+        try:
+            outs[fused] = sampler(denoiser, fx["x0"].clone().to(dev), cond=c, uc=uc)
+        finally:
+            os.environ.pop("HI3D_FUSED_STEP", None)
+    st = list(unet.runtime(dev).steppers.values())
+    assert len(st) == 1 and st[0].graph is not None, "the fused path did not run / was not captured"
+    rel, cos = stats(outs["1"], outs["0"])
+    print(f"fused vs generic: rel {rel:.2e}")
+    assert rel < 2e-3
+    rel, cos = stats(outs["1"], fx["output"])
+    assert rel < 6e-2 and cos > 0.999
