@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
+    ap.add_argument("--no-clip-parallel", action="store_true",
+                    help="N > 1: skip the extra leg that runs ONE clip over all GPUs (CFG split x frame<->space all-to-all, RCCL)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,10 +230,59 @@ def main():
 
     if cpu_sd is not None:
         out["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
+    if use_dist and world > 1 and not a.no_clip_parallel:
+        # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
+        # single 16/32-view clip faster: CFG pair x frame<->space groups, all collectives over RCCL
+        try:
+            out["clip_parallel"] = clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, ms_per_step)
+        except Exception as e:            # never lose the headline line to the optional leg
+            out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
+
+
+def clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, replica_ms):
+    """One clip on all `world` GPUs: 2 (CFG halves) x world/2 (frame<->space all-to-all groups) when world is
+    even, else 1 x world.  Every rank holds the same conditioning (seed 0) and the full 4 MB latent; per step:
+    76 all-to-alls + 44 GroupNorm sum all-reduces inside each half, one all-gather of the network output."""
+    import torch.distributed as dist
+    from hi3d_hip import synth
+    from hi3d_hip.parallel import ClipParallelStepper
+    cfg_split = 2 if world % 2 == 0 else 1
+    sp = world // cfg_split
+    if T % sp or (lat // 8) ** 2 % sp:
+        return {"skipped": f"frames ({T}) / lowest-level pixels ({(lat // 8) ** 2}) not divisible by sp={sp}"}
+    stepper = ClipParallelStepper(unet, sampler.guider, T, cfg=cfg_split)
+    x0, c, uc = synth.synth_conditioning(T, lat, lat, stage=stage, seed=0)
+    c = {k: v.to(dev) for k, v in c.items()}
+    uc = {k: v.to(dev) for k, v in uc.items()}
+    sigmas = sampler.discretization(sampler.num_steps, device=dev)
+    x = (x0.to(dev) * torch.sqrt(1.0 + sigmas[0] ** 2.0)).contiguous()
+    ioi = torch.zeros(2 // cfg_split, T, device=dev)
+    n = len(sigmas) - 1
+    for i in range(2):
+        x = stepper.step(x, sigmas, i % n, c, uc, ioi)
+    c0 = (stepper.comm.n_switches, stepper.comm.n_allreduce, stepper.comm.bytes_moved, stepper.gather_bytes)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        x = stepper.step(x, sigmas, i % n, c, uc, ioi)
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if not torch.isfinite(x).all():
+        raise RuntimeError("non-finite latents in the clip-parallel leg")
+    ms = el.item() / a.steps * 1e3
+    k = a.steps
+    return {"mapping": f"cfg{cfg_split} x sp{sp}", "ms_per_step": round(ms, 2), "steps_per_s_one_clip": round(1e3 / ms, 4),
+            "speedup_vs_one_gpu_replica": round(replica_ms / ms, 3), "scaling": "strong",
+            "all_to_all_per_step": (stepper.comm.n_switches - c0[0]) // k,
+            "gn_allreduce_per_step": (stepper.comm.n_allreduce - c0[1]) // k,
+            "all_to_all_bytes_sent_per_rank_per_step": (stepper.comm.bytes_moved - c0[2]) // k,
+            "all_gather_bytes_received_per_rank_per_step": (stepper.gather_bytes - c0[3]) // k,
+            "transport": "RCCL (torch.distributed nccl backend)"}
 
 
 def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):

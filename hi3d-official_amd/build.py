@@ -5,6 +5,7 @@ container; the resulting .so sits in-tree (git-ignored) and travels to the GPU b
 """
 import glob
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -15,7 +16,8 @@ LIB = os.path.join(ROOT, "hi3d_hip", "libhi3d_hip.so")
 STAMP = LIB + ".stamp"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = os.path.join(ROOT, "hi3d_hip", "kernel_resources.json")
 
 
 def _sources():
@@ -30,6 +32,36 @@ def _digest():
             h.update(f.encode() + b"\0" + fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
+
+
+def _collect_resources(out, table):
+    """Pull hipcc's -Rpass-analysis=kernel-resource-usage remarks into {kernel: {vgprs, agprs, scratch, occupancy, lds}};
+    returns the compiler output without those remarks."""
+    import re
+    rest, name = [], None
+    for line in out.splitlines():
+        if "[-Rpass-analysis=kernel-resource-usage]" not in line:
+            if not re.match(r"^\s*\d*\s*\|", line):          # (source excerpt / caret lines of a remark)
+                rest.append(line)
+            continue
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            table[name] = {}
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"),
+                         ("sgprs", r" SGPRs: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                table[name][key] = int(m.group(1))
+    return "\n".join(rest)
+
+
+def _spill_tolerated(mangled):
+    """The 256 x 320 tile (WM=4, NT=10) is only dispatched for the GEGLU epilogue (no scratch there); its affine /
+    conv instantiations exist for HI3D_GEMM_VARIANT=5 experiments and are known to spill."""
+    return "gemm_bf16_kernelILi4ELi10E" in mangled
 
 
 def build(force=False, verbose=True):
@@ -47,12 +79,21 @@ def build(force=False, verbose=True):
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
+    resources = {}
     for src, p in procs:
         out = p.communicate()[0].decode()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out, file=sys.stderr)
+        rest = _collect_resources(out, resources)
+        if verbose and rest.strip():
+            print(rest, file=sys.stderr)
+    with open(RESOURCES, "w") as fh:
+        json.dump(resources, fh, indent=0, sort_keys=True)
+    spilled = sorted(k for k, v in resources.items() if v.get("scratch", 0) and not _spill_tolerated(k))
+    if spilled:
+        # a kernel edit that pushes a hot instantiation into scratch costs 2-3x (measured: the conv gathers
+        # went 44 -> 133 ms/step with 32 B/lane of scratch) and is invisible in tests -- fail the build instead
+        raise RuntimeError("register spills (scratch) in: " + ", ".join(spilled))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:

@@ -28,7 +28,6 @@ struct GemmParams {
   int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8;
   int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW, pad;
   int nbm, nbn;
-  int korder;     // conv gathers: 0 = K walks taps outermost (tap, channel chunk); 1 = channel chunk outermost, taps innermost
 };
 
 constexpr int BK = 64;
@@ -173,10 +172,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (LDS_AS void*)(sB + q * 1024), 16, b_voff[i],
                                                  AMODE == HI3D_A_DENSE ? kt * (BK * 2) : (tap * p.Cin + c0) * 2, 0, 0);
     }
-    if (AMODE != HI3D_A_DENSE) {
-      if (p.korder) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) { tap = 0; c0 += BK; } }
-      else { c0 += BK; if (c0 >= p.Cin) { c0 = 0; ++tap; } }
-    }
+    // K walks the taps INNERMOST: the 9 (3) shifted reads of one 64-channel slab of the input happen in
+    // consecutive K steps, in every block of the wave front at about the same time, so a slab comes from
+    // HBM / the fabric once and the other taps hit L2.  (Round 1 walked taps outermost and re-fetched the
+    // input per tap: FETCH_SIZE 6.5x the algorithmic bytes.)
+    if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) { tap = 0; c0 += BK; } }
   };
 
   // ---- fragment read addresses (bytes within a stage)
@@ -534,12 +534,6 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // K is short, and 12-16 % from the 256 x 320 tile (variant 5) at K >= 640; plain GEMMs gain
   // 3-7 % from the 256-row tile when both K and N are long; everything else, and every conv,
   // is fastest at 0.
-  // K order of the conv gathers.  Taps innermost: the 9 (3) shifted reads of one 64-channel slab of the
-  // input happen in consecutive K steps, in every block of the wave front at about the same time, so the
-  // slab is fetched from HBM / the fabric once and the other taps hit L2 (tap-outermost re-fetched it per
-  // tap: PMC FETCH_SIZE 6.5x the algorithmic bytes).
-  p.korder = 1;
-  if (const char* e = getenv("HI3D_CONV_KORDER")) p.korder = atoi(e) ? 1 : 0;
   int variant = 0;
   if (d->amode == HI3D_A_DENSE) {
     if (d->epi == HI3D_EPI_GEGLU) variant = (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);

@@ -117,6 +117,39 @@ __global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_finalize_kernel(const fl
   }
 }
 
+// ---- split form for a GroupNorm whose instance is spread over several GPUs (the 3-D time_stack norm
+// of a space-sharded clip, hi3d_hip.parallel.FrameSpaceGroup): pass 1 as above, then
+//   gn_reduce      : fixed-order fp64 combine of this GPU's partials -> sums[inst][32][2] (double)
+//   (all-reduce of `sums` over the group: the caller's collective)
+//   gn_from_sums   : (mean, rstd) from the global sums and the GLOBAL element count
+// and gn_apply as above.
+__global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_reduce_kernel(const float* __restrict__ partial,
+                                                                      double* __restrict__ sums, int nblk) {
+  const int inst = blockIdx.x, tid = threadIdx.x & 63, part = threadIdx.x >> 6;
+  __shared__ double sh[GN_FIN_PARTS][64];
+  double acc = 0.0;
+  for (int b = part; b < nblk; b += GN_FIN_PARTS) acc += (double)partial[((long)inst * nblk + b) * 64 + tid];
+  sh[part][tid] = acc;
+  __syncthreads();
+  if (part == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < GN_FIN_PARTS; ++q) tot += sh[q][tid];
+    sums[inst * 64 + tid] = tot;
+  }
+}
+
+__global__ void gn_from_sums_kernel(const double* __restrict__ sums, float* __restrict__ stats, int n,
+                                    double inv_count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over inst * 32 groups
+  if (i >= n) return;
+  const double mean = sums[2 * i] * inv_count;
+  double var = sums[2 * i + 1] * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 template <bool SILU>
 __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -261,6 +294,47 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   HI3D_LAUNCH_CHECK();
   const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
   const int ablk = (P + appb - 1) / appb;
+  if (apply_silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_groupnorm_partial_sums(const void* x, float* ws, double* sums, int32_t inst, int32_t P,
+                                           int32_t C, void* stream) {
+  if (!x || !ws || !sums) HI3D_FAIL(HI3D_EINVAL, "groupnorm_partial_sums: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (((uintptr_t)x & 15) || ((uintptr_t)sums & 7)) HI3D_FAIL(HI3D_EALIGN, "groupnorm_partial_sums: misaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int ppb = gn_ppb(inst, P);
+  const int nblk = (P + ppb - 1) / ppb;
+  const int nthr = gn_threads(C);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, ws, P, C, nblk, ppb);
+  HI3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_reduce_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, ws, sums, nblk);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_groupnorm_apply_sums(const void* x, void* y, const float* gamma, const float* beta,
+                                         const double* sums, float* ws, int32_t inst, int32_t P, int32_t C,
+                                         int64_t count_per_group, float eps, int32_t apply_silu, void* stream) {
+  if (!x || !y || !gamma || !beta || !sums || !ws) HI3D_FAIL(HI3D_EINVAL, "groupnorm_apply_sums: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0 || count_per_group <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float* stats = ws;                         // inst * 64 floats
+  const int n = inst * 32;
+  hipLaunchKernelGGL(gn_from_sums_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, stats, n, 1.0 / (double)count_per_group, eps);
+  HI3D_LAUNCH_CHECK();
+  const int ppb = gn_ppb(inst, P);
+  const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
+  const int ablk = (P + appb - 1) / appb;
+  const int nthr = gn_threads(C);
   if (apply_silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
   else

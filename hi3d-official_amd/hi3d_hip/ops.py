@@ -206,6 +206,29 @@ def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
     return out
 
 
+def groupnorm_silu_sharded(x, gamma, beta, inst, P, C, eps, allreduce_, world, silu=True, out=None):
+    """GroupNorm(32)[+SiLU] of an instance whose P positions are this rank's share of world * P:
+    local partial sums -> allreduce_(sums) (in place, SUM over the group) -> normalise with the global
+    statistics.  x: bf16 [inst*P, C]."""
+    _chk_dev(x, gamma, beta, out)
+    assert x.is_contiguous() and x.numel() == inst * P * C
+    if out is None:
+        out = torch.empty_like(x)
+    n = _lib.hi3d_gn_workspace_floats(inst, P, C)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 16), device=x.device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    sums = torch.empty((inst, 32, 2), device=x.device, dtype=torch.float64)
+    _l.check(_lib.hi3d_groupnorm_partial_sums(_p(x), _p(ws), _p(sums), inst, P, C, _stream()), "hi3d_groupnorm_partial_sums")
+    allreduce_(sums)
+    _l.check(_lib.hi3d_groupnorm_apply_sums(_p(x), _p(out), _p(gamma), _p(beta), _p(sums), _p(ws), inst, P, C,
+                                            int(world) * P * (C // 32), float(eps), 1 if silu else 0, _stream()),
+             "hi3d_groupnorm_apply_sums")
+    return out
+
+
 def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum_out=None, out=None):
     _chk_dev(x, gamma, beta, addvec, sum_out, out)
     if out is None:

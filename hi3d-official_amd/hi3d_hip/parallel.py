@@ -9,8 +9,16 @@ What shards without a data-path collective, and what does not (SURVEY.md section
   * VAE decode is per frame            -> frames sharded over all ranks, ONE all-gather
     of the decoded frames at the hand-off (the north_star's "RCCL all-gather at VAE
     decode")                                                          -> decode_sharded
-  * frames INSIDE the UNet are coupled (Conv3d (3,1,1), GroupNorm over t,h,w, temporal
-    attention): frame<->space all-to-all re-sharding is future work, not faked here.
+  * frames INSIDE the UNet are coupled by the temporal sub-blocks only -- Conv3d (3,1,1)
+    (video_model.py:42-55), GroupNorm over (t,h,w) (util.py:274-276 on 'b c t h w'), temporal
+    attention (video_attention.py:114-125) -- and those are all per-PIXEL, while the spatial
+    sub-blocks (2-D ResBlock, spatial attention, spatial feed-forward) are all per-FRAME.  So
+    one clip runs on `sp` GPUs with its activations frame-sharded [B, T/sp, S, C] in the
+    spatial sub-blocks and space-sharded [B, T, S/sp, C] in the temporal ones, switched by an
+    all-to-all (xGMI is point-to-point: every pair of GPUs has its own link, all 7 used at
+    once), plus an all-reduce of the [b, 32, 2] GroupNorm partial sums  -> FrameSpaceGroup
+    (2 switches per VideoResBlock / SpatialVideoTransformer, 76 per step).
+    With the CFG split on top the recommended 8-GPU mapping of ONE clip is 2 (CFG) x 4 (sp).
 """
 import torch
 import torch.distributed as dist
@@ -100,3 +108,169 @@ class SplitCFGGuider:
         both = x_half.new_empty((2 * x_half.shape[0],) + tuple(x_half.shape[1:]))    # uncond || cond
         dist.all_gather_into_tensor(both, x_half.contiguous(), group=self.group)
         return self.base(both, sigma)
+
+
+class FrameSpaceGroup:
+    """Re-sharding of one clip's channels-last activations between
+
+        frame-sharded  rows (b, t_local, s)   [B * T/w * S, C]    spatial sub-blocks (per-frame ops)
+        space-sharded  rows (b, t, s_local)   [B * T * S/w, C]    temporal sub-blocks (per-pixel ops)
+
+    over the `w` ranks of `group`.  Rank r owns frames [r T/w, (r+1) T/w) in the first
+    layout and pixels [r S/w, (r+1) S/w) in the second.  Works on any device / backend: RCCL on the
+    GPUs, gloo in the CPU tests (and, for the single-GPU 2-process parity test, gloo with the payload
+    staged through the host).  Counts what it moves (`bytes_moved`, `n_switches`, `n_allreduce`)."""
+
+    def __init__(self, T, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if T % self.world:
+            raise ValueError(f"num_video_frames ({T}) must be a multiple of the frame-parallel degree ({self.world})")
+        self.T, self.Tl = T, T // self.world
+        self.t_lo = self.rank * self.Tl
+        self.bytes_moved = self.n_switches = self.n_allreduce = 0
+        self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def local_frames(self, B):
+        """indices (into the (b t) frame axis of the whole batch) of this rank's frames"""
+        return torch.cat([torch.arange(b * self.T + self.t_lo, b * self.T + self.t_lo + self.Tl) for b in range(B)])
+
+    def _check(self, S):
+        if S % self.world:
+            raise ValueError(f"pixels per frame ({S}) must be a multiple of the frame-parallel degree ({self.world})")
+        return S // self.world
+
+    def _a2a(self, send):
+        recv = torch.empty_like(send)
+        if self.world == 1:
+            return send
+        if send.is_cuda and self._host_staged:          # test-only route: gloo has no device all-to-all
+            s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+            dist.all_to_all_single(r, s, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        self.n_switches += 1
+        self.bytes_moved += send.numel() * send.element_size() * (self.world - 1) // self.world
+        return recv
+
+    def frames_to_space(self, x, B, S):
+        """[B*Tl*S, C] (b tl s) -> [B*T*Sl, C] (b t sl)"""
+        w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
+        if w == 1:
+            return x
+        send = x.reshape(B, Tl, w, Sl, C).permute(2, 0, 1, 3, 4).contiguous()      # [dst][b][tl][sl][c]
+        recv = self._a2a(send)                                                     # [src][b][tl][sl][c]: src owns frames src*Tl..
+        return recv.permute(1, 0, 2, 3, 4).reshape(B * self.T * Sl, C)             # (b, (src tl) = t, sl); free when B == 1
+
+    def space_to_frames(self, x, B, S):
+        """[B*T*Sl, C] (b t sl) -> [B*Tl*S, C] (b tl s)"""
+        w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
+        if w == 1:
+            return x
+        send = x.reshape(B, w, Tl, Sl, C).permute(1, 0, 2, 3, 4).contiguous()      # [dst = owner of frames][b][tl][sl][c]
+        recv = self._a2a(send)                                                     # [src = owner of pixels][b][tl][sl][c]
+        return recv.permute(1, 2, 0, 3, 4).reshape(B * Tl * S, C)                  # (b, tl, (src sl) = s)
+
+    def allreduce_sum_(self, t):
+        """in-place sum over the group: the [b, 32, 2] GroupNorm partial sums of a space-sharded 3-D norm"""
+        if self.world > 1:
+            if t.is_cuda and self._host_staged:
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
+            self.n_allreduce += 1
+        return t
+
+
+class ClipParallelStepper:
+    """ONE clip's Euler-EDM + CFG step on cfg x sp GPUs (the recommended 8-GPU mapping is
+    2 (CFG pair) x 4 (frame <-> space groups)).  Rank r of `group` is (half, part) = divmod(r, sp):
+
+      * cfg == 2: ranks with half 0 evaluate the unconditional half of the batch, half 1 the conditional
+        one (they never mix inside the UNet); cfg == 1: every rank carries both (B = 2);
+      * inside a half, `sp` ranks share the clip through FrameSpaceGroup (all-to-all + GroupNorm all-reduce);
+      * ONE all-gather of the network output [*, 4] per step over all ranks reassembles
+        [2][T][HW][4]; the guidance + Euler update (hi3d_sampler_step_dev, 4 MB) is then done redundantly on
+        every rank, so all ranks hold the same next latent -- no broadcast.
+
+    x / the returned latent are the FULL [T,4,h,w] fp32 state (replicated, 4 MB at stage 2)."""
+
+    def __init__(self, unet, guider, T, cfg=2, group=None):
+        from . import ops  # noqa: F401  (needs the HIP library: GPU only)
+        self.unet, self.guider, self.T, self.cfg = unet, guider, T, cfg
+        self.group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if cfg not in (1, 2) or world % cfg:
+            raise ValueError(f"cfg split {cfg} does not divide the group of {world} ranks")
+        self.sp = world // cfg
+        self.half, self.part = divmod(rank, self.sp)
+        # one sub-group per CFG half for the frame<->space traffic (every rank must create every group)
+        self.sp_group = None
+        ranks_all = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+        for h in range(cfg):
+            g = dist.new_group([ranks_all[h * self.sp + q] for q in range(self.sp)])
+            if h == self.half:
+                self.sp_group = g
+        self.comm = FrameSpaceGroup(T, self.sp_group)
+        self.gather_bytes = 0
+        self._host_staged = dist.get_backend(group) == "gloo"
+        self._clip = None
+
+    def _conds(self, c, uc, dev):
+        """this rank's conditioning: its CFG half (cfg == 2) or uc || c (cfg == 1); built once per clip"""
+        key = tuple((id(d[k]), d[k]._version) for d in (c, uc) for k in sorted(d))
+        if self._clip is None or self._clip[0] != key:
+            pick = (lambda k: (uc, c)[self.half][k].to(dev)) if self.cfg == 2 else \
+                (lambda k: torch.cat((uc[k].to(dev), c[k].to(dev)), 0))
+            lo, hi = self.comm.t_lo, self.comm.t_lo + self.comm.Tl
+            cc = None
+            if c.get("concat") is not None and c["concat"].numel():
+                if self.cfg == 2:
+                    cc = (uc, c)[self.half]["concat"][lo:hi].to(dev, torch.float32)
+                else:
+                    cc = torch.cat((uc["concat"][lo:hi], c["concat"][lo:hi]), 0).to(dev, torch.float32)
+            self._clip = (key, pick("crossattn"), pick("vector"), cc, (c, uc))     # refs held: ids stay unique
+        return self._clip[1:4]
+
+    @torch.no_grad()
+    def step(self, x, sigmas, i, c, uc, image_only_indicator=None):
+        from . import ops
+        from .runtime_unet import CIN_PAD
+        dev = x.device
+        T, Tl, lo = self.T, self.comm.Tl, self.comm.t_lo
+        _, _, H, W = x.shape
+        HW, B = H * W, 2 // self.cfg
+        rt = self.unet.runtime(dev)
+        with torch.cuda.device(dev):
+            ctx, y, cc = self._conds(c, uc, dev)
+            st = rt.clip_consts(ctx, y, image_only_indicator, B * T, T)
+            sig = sigmas[i:i + 2].to(dev, torch.float32)
+            c_in = torch.rsqrt(sig[0] * sig[0] + 1.0)
+            xl = (x[lo:lo + Tl] * c_in)
+            xin = xl if B == 1 else torch.cat((xl, xl), 0)
+            if cc is not None:
+                xin = torch.cat((xin, cc), 1)
+            tok = ops.nchw_to_tokens(xin, CIN_PAD)
+            tvec = (0.25 * torch.log(sig[0])).expand(B * T).contiguous()
+            net = rt.forward_tokens(tok, B * T, H, W, tvec, st, T, sp=self.comm)            # [B*Tl*HW, 4] fp32
+            world = self.cfg * self.sp
+            full = torch.empty((world * net.shape[0], net.shape[1]), device=dev, dtype=net.dtype)   # rank-major concatenation
+            if self._host_staged:
+                hfull = torch.empty(full.shape, dtype=net.dtype)
+                dist.all_gather_into_tensor(hfull, net.cpu().contiguous(), group=self.group)
+                full.copy_(hfull)
+            else:
+                dist.all_gather_into_tensor(full, net.contiguous(), group=self.group)
+            self.gather_bytes += net.numel() * net.element_size() * (world - 1)
+            if self.cfg == 2:            # [half][part][Tl*HW][4] is already [2][T][HW][4]
+                net_full = full.reshape(2 * T * HW, net.shape[-1])
+            else:                        # [part][b][Tl*HW][4] -> [b][part][Tl*HW][4]
+                net_full = full.reshape(self.sp, 2, Tl * HW, net.shape[-1]).transpose(0, 1).reshape(2 * T * HW, net.shape[-1])
+            scale = self.guider.scale.reshape(-1).to(dev, torch.float32).contiguous()
+            out = torch.empty_like(x)
+            ops.sampler_step_dev(x.contiguous(), out, net_full.contiguous(), scale, sig.contiguous(), T, HW, net.shape[-1])
+            return out

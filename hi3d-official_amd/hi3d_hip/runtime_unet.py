@@ -258,8 +258,12 @@ class UNetRuntime:
         return self._pos_cache[key]
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all):
-        W, HW, B = self.W, H * Wd, F_ // T
+    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all, sp=None, emb_full=None, B=None):
+        """VideoResBlock (video_model.py:62-81).  F_: frames held by this GPU.  With `sp` (a
+        hi3d_hip.parallel.FrameSpaceGroup) the spatial ResBlock runs on this GPU's frames, the temporal one
+        on its pixels of ALL frames (all-to-all before and after, GroupNorm sums all-reduced)."""
+        W, HW = self.W, H * Wd
+        B = F_ // T if B is None else B
         M = F_ * HW
         geo = dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0)
         eo, _ = self.emb_slices[p]
@@ -274,42 +278,63 @@ class UNetRuntime:
         # temporal ResBlock on the same memory: GroupNorm over (t,h,w) per clip, Conv3d (3,1,1)
         q = p + ".time_stack"
         eo, _ = self.emb_slices[q]
-        tg = dict(T=T, HW=HW, Cin=Cout)
-        h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5)
-        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=M, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
-                     rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, convt3=tg)
-        h = ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], B, T * HW, Cout, 1e-5)
+        if sp is None:
+            HWt, emb_t = HW, emb_all
+            gn3 = lambda t, k: ops.groupnorm_silu(t, W[k + ".g"], W[k + ".b"], B, T * HW, Cout, 1e-5)
+        else:                                   # rows (b t s_local): every frame, this GPU's pixels
+            HWt, emb_t = HW // sp.world, emb_full
+            xs = sp.frames_to_space(xs, B, HW)
+            gn3 = lambda t, k: ops.groupnorm_silu_sharded(t, W[k + ".g"], W[k + ".b"], B, T * HWt, Cout, 1e-5,
+                                                          sp.allreduce_sum_, sp.world)
+        Mt = B * T * HWt
+        tg = dict(T=T, HW=HWt, Cin=Cout)
+        h = gn3(xs, q + ".in_layers.0")
+        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
+                     rowvec=emb_t[:, eo:], ldrv=self.emb_total, rows_per_group=HWt, convt3=tg)
+        h = gn3(h, q + ".out_layers.0")
         # alpha*x_s + (1-alpha)*(x_s + h_t)  ==  x_s + (1-alpha)*h_t     (video_model.py:77-79)
-        return ops.gemm(h, W[q + ".out_layers.3.w"], M=M, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
-                        a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HW, convt3=tg)
+        out = ops.gemm(h, W[q + ".out_layers.3.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
+                       a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HWt, convt3=tg)
+        return out if sp is None else sp.space_to_frames(out, B, HW)
 
-    def _transformer(self, p, x, C, F_, S, T, cond, a1_all, a_all):
-        W, B, M, Hh = self.W, F_ // T, F_ * S, C // 64
-        sp, tp = p + ".transformer_blocks.0", p + ".time_stack.0"
+    def _transformer(self, p, x, C, F_, S, T, cond, a1_all, a_all, sp=None, B=None):
+        """SpatialVideoTransformer (video_attention.py:230-301).  With `sp`: spatial block on this GPU's
+        frames, temporal block (+ AlphaBlender) on its pixels of all frames."""
+        W, M, Hh = self.W, F_ * S, C // 64
+        B = F_ // T if B is None else B
+        sp_, tp = p + ".transformer_blocks.0", p + ".time_stack.0"
         xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False)
         h = self._linear(xn, p + ".proj_in", M)
         # --- spatial block (attention.py:551-572)
-        n = ops.layernorm(h, W[sp + ".norm1.g"], W[sp + ".norm1.b"], M, C)
-        qkv = ops.gemm(n, W[sp + ".qkv.w"], M=M, N=3 * C, K=C)
+        n = ops.layernorm(h, W[sp_ + ".norm1.g"], W[sp_ + ".norm1.b"], M, C)
+        qkv = ops.gemm(n, W[sp_ + ".qkv.w"], M=M, N=3 * C, K=C)
         a = ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
-        h = ops.gemm(a, W[sp + ".o.w"], M=M, N=C, K=C, bias=W[sp + ".o.b"], R1=h,
-                     rowvec=cond[sp], rows_per_group=S)                     # + attn1 + attn2 (one token)
-        n = ops.layernorm(h, W[sp + ".norm3.g"], W[sp + ".norm3.b"], M, C)
-        h = self._ff(n, sp + ".ff", M, C, R1=h)
-        # --- temporal block (video_attention.py:109-140), rows stay in (b t) s order
+        h = ops.gemm(a, W[sp_ + ".o.w"], M=M, N=C, K=C, bias=W[sp_ + ".o.b"], R1=h,
+                     rowvec=cond[sp_], rows_per_group=S)                    # + attn1 + attn2 (one token)
+        n = ops.layernorm(h, W[sp_ + ".norm3.g"], W[sp_ + ".norm3.b"], M, C)
+        h = self._ff(n, sp_ + ".ff", M, C, R1=h)
+        # --- temporal block (video_attention.py:109-140): rows stay in (b t) s order -- or, frame-parallel,
+        # become (b t s_local) through the all-to-all
+        St = S
+        if sp is not None:
+            St = S // sp.world
+            h = sp.frames_to_space(h, B, S)
+        Mt = B * T * St
         xm = torch.empty_like(h)
-        n = ops.layernorm(h, W[tp + ".norm_in.g"], W[tp + ".norm_in.b"], M, C, addvec=self._pos_emb(p, C, B, T),
-                          rows_per_group=S, sum_out=xm)                      # xm = h + frame-position emb
-        xm = self._ff(n, tp + ".ff_in", M, C, R1=xm)
-        n = ops.layernorm(xm, W[tp + ".norm1.g"], W[tp + ".norm1.b"], M, C)
-        qkv = ops.gemm(n, W[tp + ".qkv.w"], M=M, N=3 * C, K=C)
-        a = ops.attention_temporal_fused_qkv(qkv, B, T, S, Hh)
-        xm = ops.gemm(a, W[tp + ".o.w"], M=M, N=C, K=C, bias=W[tp + ".o.b"], R1=xm,
-                      rowvec=cond[tp], rows_per_group=T * S)
-        n = ops.layernorm(xm, W[tp + ".norm3.g"], W[tp + ".norm3.b"], M, C)
+        n = ops.layernorm(h, W[tp + ".norm_in.g"], W[tp + ".norm_in.b"], Mt, C, addvec=self._pos_emb(p, C, B, T),
+                          rows_per_group=St, sum_out=xm)                     # xm = h + frame-position emb
+        xm = self._ff(n, tp + ".ff_in", Mt, C, R1=xm)
+        n = ops.layernorm(xm, W[tp + ".norm1.g"], W[tp + ".norm1.b"], Mt, C)
+        qkv = ops.gemm(n, W[tp + ".qkv.w"], M=Mt, N=3 * C, K=C)
+        a = ops.attention_temporal_fused_qkv(qkv, B, T, St, Hh)
+        xm = ops.gemm(a, W[tp + ".o.w"], M=Mt, N=C, K=C, bias=W[tp + ".o.b"], R1=xm,
+                      rowvec=cond[tp], rows_per_group=T * St)
+        n = ops.layernorm(xm, W[tp + ".norm3.g"], W[tp + ".norm3.b"], Mt, C)
         i = self.mix_index[p]
         # AlphaBlender: alpha*h + (1-alpha)*(ff(..)+xm)                      (video_attention.py:290-294)
-        h = self._ff(n, tp + ".ff", M, C, R1=xm, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=S)
+        h = self._ff(n, tp + ".ff", Mt, C, R1=xm, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=St)
+        if sp is not None:
+            h = sp.space_to_frames(h, B, S)
         return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x)
 
     def _ff(self, n, key, M, C, **epi):
@@ -323,18 +348,35 @@ class UNetRuntime:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward_tokens(self, x_tok, F_, H, Wd, timesteps, st, T):
+    def forward_tokens(self, x_tok, F_, H, Wd, timesteps, st, T, sp=None):
         """x_tok: bf16 [F*H*W, 64] (input channels zero-padded) -> fp32 [F*H*W, 4(out_channels)].
-        timesteps: fp32 device [F]; st: clip_consts(...).  Issues HIP kernels only (graph-capturable)."""
+        timesteps: fp32 device [F]; st: clip_consts(...).  Issues HIP kernels only (graph-capturable).
+
+        Frame-parallel (`sp` = hi3d_hip.parallel.FrameSpaceGroup over w GPUs): F, timesteps and
+        st still describe the WHOLE batch of B*T frames; x_tok holds this GPU's B*T/w frames (clip-major)
+        and so does the result."""
         W, mc = self.W, self.mc
         if F_ % T:
             raise ops._l.Hi3dError("batch is not a multiple of num_video_frames")
+        B_all = F_ // T
         # ---- embeddings (video_model.py:456-469): emb = time_embed(t) + label_emb(y)
         te = ops.timestep_embedding(timesteps, mc, 10000.0, out_bf16=True)
         h = self._linear(te, "time_embed.0", F_, out_fp32=True)
         emb = self._linear(ops.silu_to_bf16(h), "time_embed.2", F_, out_fp32=True, rowvec=st["lab"], rows_per_group=1)
         emb_all = self._linear(ops.silu_to_bf16(emb), "emb_all", F_, out_fp32=True)     # all 44 emb_layers at once
         cond, a_all, a1_all = st["cond"], st["a_all"], st["a1_all"]
+        emb_full = emb_all
+        if sp is not None and sp.world > 1:
+            idx = sp.local_frames(B_all).to(self.dev)
+            emb_all = emb_full.index_select(0, idx)                 # rows of this GPU's frames (spatial sub-blocks)
+            cond = dict(cond)
+            for pt, _ in self.transformers:                          # per-frame vectors of the spatial blocks
+                k = pt + ".transformer_blocks.0"
+                cond[k] = st["cond"][k].index_select(0, idx)
+            F_ = idx.numel()
+        else:
+            sp = None
+        kw = dict(sp=sp, B=B_all)
 
         blocks_in, middle, blocks_out = self.layout
         h, hs = x_tok, []
@@ -349,10 +391,10 @@ class UNetRuntime:
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
                     cur["C"] = mc
                 elif L[0] == "res":
-                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all)
+                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all, emb_full=emb_full, **kw)
                     cur["C"] = L[2]
                 elif L[0] == "attn":
-                    h = self._transformer(p, h, L[1], F_, Hc * Wc, T, cond, a1_all, a_all)
+                    h = self._transformer(p, h, L[1], F_, Hc * Wc, T, cond, a1_all, a_all, **kw)
                 elif L[0] == "down":
                     Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
                     h = ops.gemm(h, W[p + ".w"], M=F_ * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"],

@@ -160,6 +160,19 @@ int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float*
                         float* ws, int32_t inst, int32_t P, int32_t C,
                         float eps, int32_t apply_silu, void* stream);
 
+/* GroupNorm(32)+SiLU whose instance is spread over several GPUs -- the 3-D time_stack norm
+ * (statistics over t,h,w: util.py:274-276 applied to 'b c t h w', video_model.py:71-76) of a clip
+ * whose pixels are sharded over a frame-parallel group.  Two calls around the caller's
+ * all-reduce(SUM) of `sums`:
+ *   hi3d_groupnorm_partial_sums : sums[inst][32][2] (double) = this GPU's (sum, sum of squares) per group
+ *   hi3d_groupnorm_apply_sums   : y = [silu](x normalised with the GLOBAL sums over count_per_group elements)
+ * ws: hi3d_gn_workspace_floats(inst, P, C) floats, as for hi3d_groupnorm_silu.                  */
+int hi3d_groupnorm_partial_sums(const void* x, float* ws, double* sums, int32_t inst, int32_t P,
+                                int32_t C, void* stream);
+int hi3d_groupnorm_apply_sums(const void* x, void* y, const float* gamma, const float* beta,
+                              const double* sums, float* ws, int32_t inst, int32_t P, int32_t C,
+                              int64_t count_per_group, float eps, int32_t apply_silu, void* stream);
+
 /* LayerNorm over the last dim C of x[R][C] (sgm/modules/attention.py:520-522;
  * video_attention.py:51,79,93-94), with an optional fused per-group pre-add:
  *   s = x[r] + addvec[r / rows_per_group]   (addvec fp32 [G][C] or NULL)

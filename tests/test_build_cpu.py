@@ -1,0 +1,27 @@
+"""Build hygiene that no numerics test can see: a hot kernel instantiation that spills registers to scratch
+still computes the right answer -- 2-3x slower (round 2: one extra runtime branch in the conv K walk put 32
+B/lane of scratch into every conv gather and took the step from 234 to 351 ms).  hi3d-official_amd/build.py
+records hipcc's kernel-resource-usage remarks; this checks them."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = os.path.join(ROOT, "hi3d-official_amd", "hi3d_hip", "kernel_resources.json")
+
+
+def test_no_hot_kernel_spills_to_scratch():
+    if not os.path.exists(RES):
+        pytest.skip("library not built here (python hi3d-official_amd/build.py)")
+    res = json.load(open(RES))
+    assert len(res) > 40
+    gemm = {k: v for k, v in res.items() if "gemm_bf16_kernel" in k}
+    assert gemm and any("ffn_geglu" in k for k in res) and any("attn_d64" in k for k in res)
+    tolerated = lambda k: "gemm_bf16_kernelILi4ELi10E" in k          # 256x320 tile, affine/conv forms: experiments only
+    spilled = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) and not tolerated(k)}
+    assert not spilled, spilled
+    # the instantiations the stage-2 step actually dispatches keep two blocks per CU (occupancy 2 with 256 threads)
+    for k, v in gemm.items():
+        if "ILi2ELi5ELi2E" in k:
+            assert v["occupancy"] >= 2 and v["vgprs"] <= 256, (k, v)

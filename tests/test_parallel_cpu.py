@@ -1,6 +1,8 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU mappings: VAE frame sharding +
-all-gather, and the CFG-pair split.  The arithmetic under test is the sharding /
-collective logic; the per-rank 'network' is an analytic stand-in (kernels need a GPU)."""
+all-gather, the CFG-pair split, and the frame <-> space re-sharding of ONE clip inside the UNet
+ -- the last one with the real network arithmetic: the CPU oracle UNet runs on every
+rank under hi3d_hip.parallel.FrameSpaceGroup and must reproduce the unsharded oracle.  (The VAE / CFG
+tests use an analytic stand-in network: what they check is the collective logic.)"""
 import os
 import socket
 
@@ -21,6 +23,7 @@ def _run(rank, world, port, fn, ret):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "hi3d-official_amd"))
+    sys.path.insert(0, root)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
@@ -103,3 +106,90 @@ def test_cfg_pair_split_matches_doubled_batch():
     for r in range(2):
         assert torch.allclose(res[r], ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(res[0], res[1])
+
+
+# ---------------------------------------------------------------- frame <-> space all-to-all
+def _reshard_job(rank, world):
+    """layout algebra of the two switches on a labelled tensor: element (b, t, s, c) must land where the
+    layouts say, and the round trip must be the identity"""
+    from hi3d_hip.parallel import FrameSpaceGroup
+    out = {}
+    for B, T, S, C in ((1, 4, 8, 3), (2, 8, 12, 2)):
+        g = FrameSpaceGroup(T)
+        Tl, Sl = T // world, S // world
+        full = torch.arange(B * T * S * C, dtype=torch.float32).reshape(B, T, S, C)
+        mine_f = full[:, rank * Tl:(rank + 1) * Tl].reshape(B * Tl * S, C)            # frame-sharded
+        mine_s = full[:, :, rank * Sl:(rank + 1) * Sl].reshape(B * T * Sl, C)         # space-sharded
+        got_s = g.frames_to_space(mine_f.clone(), B, S)
+        got_f = g.space_to_frames(mine_s.clone(), B, S)
+        back = g.space_to_frames(got_s.clone(), B, S)
+        out[(B, T)] = (torch.equal(got_s, mine_s), torch.equal(got_f, mine_f), torch.equal(back, mine_f),
+                       g.n_switches, g.bytes_moved, list(g.local_frames(B)))
+    return out
+
+
+def test_frame_space_all_to_all_layouts():
+    for world in (2, 4):
+        res = spawn(_reshard_job, world)
+        for r in range(world):
+            for (B, T), (a, b, c, n, nbytes, lf) in res[r].items():
+                assert a and b and c and n == 3
+                Tl = T // world
+                assert lf == [bb * T + r * Tl + i for bb in range(B) for i in range(Tl)]
+        # bytes: every switch ships (w-1)/w of the local shard
+        B, T, S, C = 2, 8, 12, 2
+        assert res[0][(2, 8)][4] == 3 * (B * T * S * C * 4 // world) * (world - 1) // world
+
+
+def _sharded_unet_job(rank, world):
+    import torch
+    from hi3d_hip import synth
+    from hi3d_hip.parallel import FrameSpaceGroup
+    from oracle import hi3d_oracle_sharded as OS
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_s2_ioi.pt"), weights_only=False)
+    cfg, P = fx["cfg"], fx["key_prefix"]
+    sd = synth.synth_state_dict({P + k: v for k, v in fx["shapes"].items()}, fx["weight_seed"])
+    T, H, W, B = 4, 16, 8, 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B * T, cfg["in_channels"], H, W), generator=g)
+    ctx, y = torch.randn((B, 1, 1024), generator=g), torch.randn((B, cfg["adm_in_channels"]), generator=g)
+    ioi = torch.zeros(B, T); ioi[1, 2] = 1.0
+    comm = FrameSpaceGroup(T)
+    torch.set_num_threads(2)
+    with torch.no_grad():
+        out = OS.video_unet_sharded(sd, cfg, x[comm.local_frames(B)], 0.37, ctx, y, T, ioi, comm, prefix=P)
+    return out, comm.n_switches, comm.n_allreduce, comm.bytes_moved
+
+
+def test_unet_frame_space_sharded_equals_unsharded_oracle():
+    """Two ranks, each holding half the frames (spatial sub-blocks) / half the pixels (temporal
+    sub-blocks) of the same 2-clip batch, with the 3-D GroupNorm partial-sum all-reduce: the
+    concatenation of the ranks' outputs must equal the single-process oracle forward."""
+    from hi3d_hip import synth
+    from hi3d_hip.runtime_unet import unet_layout
+    from oracle import hi3d_oracle as O
+    world = 2
+    res = spawn(_sharded_unet_job, world)
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_s2_ioi.pt"), weights_only=False)
+    cfg, P = fx["cfg"], fx["key_prefix"]
+    sd = synth.synth_state_dict({P + k: v for k, v in fx["shapes"].items()}, fx["weight_seed"])
+    T, H, W, B = 4, 16, 8, 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B * T, cfg["in_channels"], H, W), generator=g)
+    ctx, y = torch.randn((B, 1, 1024), generator=g), torch.randn((B, cfg["adm_in_channels"]), generator=g)
+    ioi = torch.zeros(B, T); ioi[1, 2] = 1.0
+    with torch.no_grad():
+        ref = O.video_unet(sd, cfg, x, torch.full((B * T,), 0.37), ctx, y, T, ioi, prefix=P)
+    Tl = T // world
+    got = torch.empty_like(ref)
+    for r in range(world):
+        idx = torch.cat([torch.arange(b * T + r * Tl, b * T + (r + 1) * Tl) for b in range(B)])
+        got[idx] = res[r][0]
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f"frame<->space sharded oracle vs unsharded: rel {err:.2e}")
+    assert err < 2e-5
+    # the plan: two switches per VideoResBlock and per SpatialVideoTransformer, two sum all-reduces per 3-D ResBlock
+    bi, mid, bo = unet_layout(cfg)
+    layers = [L for blk in bi + [mid] + bo for L in blk]
+    nres, nattn = sum(L[0] == "res" for L in layers), sum(L[0] == "attn" for L in layers)
+    assert res[0][1] == 2 * (nres + nattn) and res[0][2] == 2 * nres
