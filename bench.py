@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["s1", "s2", "vae"], default="s2")
     ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--attn", choices=["bf16", "fp8qk"], default="bf16",
+                    help="fp8qk: BASELINE config 5 -- spatial attention scores on the fp8 (e4m3, MX-scaled) matrix path, "
+                         "P V and everything else bf16; reported as dtype fp8-qk/bf16 (reduced precision, own tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
@@ -87,6 +90,8 @@ def main():
 
     if a.config == "vae":
         return bench_vae(a, rank, world, dev, use_dist)
+    if a.attn == "fp8qk":
+        os.environ["HI3D_ATTN_FP8QK"] = "1"
     stage = 1 if a.config == "s1" else 2
     T = a.views
     lat = 64 if stage == 1 else 128
@@ -164,7 +169,7 @@ def main():
                   else f"denoise-steps/sec (UNet fwd) at {T} views x {lat * 8}^2",
         "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if a.attn == "bf16" else "fp8-qk/bf16", "data": "synthetic",
         "config": {"workload": f"Hi3D stage-{stage} VideoUNet sampler step, {T} views @ {lat * 8}x{lat * 8} "
                                f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
                                "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
@@ -196,7 +201,7 @@ def main():
         # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
         g = [d for f, d in summ.items() if f.startswith("gemm_")]   # (the fused feed-forward kernel is listed on its own line)
         g_ms, g_fl, g_n = sum(d["ms"] for d in g), sum(d["flops"] for d in g), sum(d["launches"] for d in g)
-        at = summ.get("attn_d64", dict(ms=0.0, flops=0.0, launches=1))
+        at = summ.get("attn_d64", summ.get("attn_d64_fp8qk", dict(ms=0.0, flops=0.0, launches=1)))
         dom_is_gemm = g_ms >= at["ms"]
         k_ms, k_fl, k_n = (g_ms, g_fl, g_n) if dom_is_gemm else (at["ms"], at["flops"], at["launches"])
         ach = k_fl / (k_ms * 1e-3) / 1e12
@@ -215,8 +220,10 @@ def main():
                            "timing": f"HIP events around every launch over the {a.steps} steps after the timed region "
                                      "(the timed steps are graph replays)"}
         out["kernels_ms_per_step"] = {f: round(d["ms"] / a.steps, 3) for f, d in fams}
-        if "attn_d64" in summ:
-            d = summ["attn_d64"]
+        for fam in ("attn_d64", "attn_d64_fp8qk"):
+            if fam not in summ:
+                continue
+            d = summ[fam]
             out["attention_mfma"] = {"achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
                                      "unit": "TFLOP/s", "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
         for fam in ("groupnorm_silu", "layernorm"):

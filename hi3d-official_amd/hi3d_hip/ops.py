@@ -3,6 +3,8 @@ current HIP stream, every FLOP runs in libhi3d_hip.so.
 
 Activations: torch.bfloat16, channels-last tokens [frames, H*W, C] (contiguous).
 """
+import os
+
 import torch
 
 from . import lib as _l
@@ -166,6 +168,28 @@ def self_attention_fused_qkv(qkv, B, S, H, scale=None, q_prescaled=False):
     return attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
 
 
+def self_attention_fused_qkv_fp8qk(qkv, B, S, H):
+    """self_attention_fused_qkv(..., q_prescaled=True) with the score product on the fp8 matrix path (BASELINE
+    config 5): q | k are quantised to e4m3 with MX block scales (one pass), S = Q K^T runs at twice the bf16
+    MFMA rate, softmax and P V are unchanged.  qkv: [B*S, 3*H*64] bf16, q carrying Q_PRESCALE."""
+    C = H * 64
+    assert qkv.shape == (B * S, 3 * C) and qkv.is_contiguous()
+    _chk_dev(qkv)
+    vt = transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+    ws = torch.empty(_lib.hi3d_attn_fp8_workspace_bytes(B, H, S), device=qkv.device, dtype=torch.uint8)
+    out = torch.empty((B * S, C), device=qkv.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_attn_quant_qk(_p(qkv), _p(ws), B, H, S, 3 * C, _stream()), "hi3d_attn_quant_qk")
+    if prof:
+        prof.end("quant_qk", 0.0, 2.0 * 2 * B * S * C + 2 * B * S * (C + 2 * H), t0)
+        t0 = prof.begin()
+    _l.check(_lib.hi3d_attn_d64_fp8qk(_p(ws), _p(vt), _p(out), B, H, S, vt.shape[-1], C, _stream()), "hi3d_attn_d64_fp8qk")
+    if prof:
+        prof.end("attn_d64_fp8qk", 4.0 * B * H * S * S * 64, B * H * 64.0 * (1 * S + 1 * S + 2 * S + 2 * S), t0)
+    return out
+
+
 def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
     """qkv: [(B*T*S), 3*H*64] bf16 in frame-major (b t s) row order."""
     C = H * 64
@@ -185,12 +209,32 @@ def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
 _gn_ws = {}
 
 
+GN_SPLIT_BYTES = int(float(os.environ.get("HI3D_GN_SPLIT_MB", "0")) * (1 << 20))
+
+
 def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
-    """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32)."""
+    """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32).
+
+    The kernel reads x twice (statistics, then normalise).  With HI3D_GN_SPLIT_MB=<n> a tensor larger than n MiB
+    is processed in runs of whole instances of at most n MiB, so that the second read of a run still finds
+    it in the 256 MB Infinity Cache instead of going back to HBM (A/B switch, off by default)."""
     _chk_dev(x, gamma, beta, out)
     assert x.is_contiguous() and x.numel() == inst * P * C
     if out is None:
         out = torch.empty_like(x)
+    per = P * C * 2
+    if GN_SPLIT_BYTES and inst > 1 and inst * per > GN_SPLIT_BYTES:
+        step = max(1, GN_SPLIT_BYTES // per)
+        if step < inst:
+            xv, ov = x.reshape(inst, P * C), out.reshape(inst, P * C)
+            for lo in range(0, inst, step):
+                n = min(step, inst - lo)
+                _groupnorm_silu(xv[lo:lo + n], gamma, beta, n, P, C, eps, silu, ov[lo:lo + n])
+            return out
+    return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out)
+
+
+def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out):
     n = _lib.hi3d_gn_workspace_floats(inst, P, C)
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)

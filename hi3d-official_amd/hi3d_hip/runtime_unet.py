@@ -80,6 +80,9 @@ class UNetRuntime:
         self.layout = unet_layout(cfg)
         # HI3D_FUSED_FFN=0 falls back to the two-GEMM feed-forward (A/B switch; both are HIP paths)
         self.fused_ffn = os.environ.get("HI3D_FUSED_FFN", "1") != "0"
+        # HI3D_ATTN_FP8QK=1: spatial attention scores on the fp8 matrix path (BASELINE config 5; reduced precision,
+        # own tolerance) instead of bf16
+        self.attn_fp8qk = os.environ.get("HI3D_ATTN_FP8QK", "0") == "1"
         self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
         self._pos_cache = {}
         self.steppers = {}      # (T, H, W) -> hi3d_hip.fused_step.FusedStepper
@@ -308,7 +311,8 @@ class UNetRuntime:
         # --- spatial block (attention.py:551-572)
         n = ops.layernorm(h, W[sp_ + ".norm1.g"], W[sp_ + ".norm1.b"], M, C)
         qkv = ops.gemm(n, W[sp_ + ".qkv.w"], M=M, N=3 * C, K=C)
-        a = ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
+        a = ops.self_attention_fused_qkv_fp8qk(qkv, F_, S, Hh) if self.attn_fp8qk else \
+            ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
         h = ops.gemm(a, W[sp_ + ".o.w"], M=M, N=C, K=C, bias=W[sp_ + ".o.b"], R1=h,
                      rowvec=cond[sp_], rows_per_group=S)                    # + attn1 + attn2 (one token)
         n = ops.layernorm(h, W[sp_ + ".norm3.g"], W[sp_ + ".norm3.b"], M, C)

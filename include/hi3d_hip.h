@@ -126,6 +126,20 @@ int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
                   int32_t ldq, int32_t ldk, int32_t ld_vt /* = S_pad */, int32_t ldo,
                   float scale, void* stream);
 
+/* Spatial self-attention with the score product on the CDNA4 fp8 matrix path (BASELINE.json config 5,
+ * "fp8 MFMA attention + bf16 conv"): same attention as hi3d_attn_d64 (attention.py:332-336 / 427-439) with
+ * S = Q K^T computed by v_mfma_scale_f32_32x32x64_f8f6f4 on OCP e4m3 operands with MX block scales
+ * (one e8m0 power-of-two scale per 32 elements of a row); softmax and P V stay bf16 / fp32.
+ * Reduced precision: parity with fp32 softmax attention is stated separately (tests/test_kernels_gpu.py).
+ *   hi3d_attn_fp8_workspace_bytes : size of `ws` for (B, H, S)
+ *   hi3d_attn_quant_qk  : q | k column blocks of a fused QKV tensor (bf16 [B*S][ld], q pre-multiplied by
+ *                         softmax scale * log2 e) -> ws = {q8, k8: [B][H][S_pad][64] e4m3; qs, ks: [..][2] e8m0}
+ *   hi3d_attn_d64_fp8qk : out[b][s][h*64+d] from ws and vt (hi3d_transpose_v layout), S_q = S_kv = S      */
+int64_t hi3d_attn_fp8_workspace_bytes(int32_t B, int32_t H, int32_t S);
+int hi3d_attn_quant_qk(const void* qkv, void* ws, int32_t B, int32_t H, int32_t S, int32_t ld, void* stream);
+int hi3d_attn_d64_fp8qk(const void* ws, const void* vt, void* out, int32_t B, int32_t H, int32_t S,
+                        int32_t ld_vt, int32_t ldo, void* stream);
+
 /* vt[b][h][d][s] = v[(b*S+s)*ldv + h*64 + d]  ; S_pad % 64 == 0, pad = 0    */
 int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
                      int32_t S_pad, int32_t ldv, void* stream);

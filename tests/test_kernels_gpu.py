@@ -213,6 +213,40 @@ def test_attention_d64_prescaled_q(dev):
     assert relerr(out, ref) < 2e-2
 
 
+def _mx_e4m3(x, block=64):
+    """CPU restatement of hi3d_attn_quant_qk: per `block` elements of a head row (QK_SCALE_BLOCK in
+    csrc/attention_fp8.hip), shared exponent floor(log2 amax) - 7, elements rounded to OCP e4m3 (round to
+    nearest even) -- returns the DEQUANTISED values."""
+    xb = x.reshape(*x.shape[:-1], x.shape[-1] // block, block)
+    amax = xb.abs().amax(-1, keepdim=True)
+    e = ((amax.view(torch.int32) >> 23) & 0xff).clamp(8, 254)          # biased exponent, as the kernel clamps it
+    sc = torch.pow(2.0, (e - 127 - 7).float())
+    return ((xb / sc).to(torch.float8_e4m3fn).float() * sc).reshape(x.shape)
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 1000), (1, 1, 70), (1, 3, 2048)])
+def test_attention_d64_fp8qk(dev, B, H, S):
+    """BASELINE config 5: score product on the fp8 matrix path (e4m3 Q / K with MX block scales), bf16 P V.
+    (a) the kernel computes exactly the stated quantised attention: vs fp32 attention on the SAME
+        dequantised q / k, usual attention tolerance 2e-2;
+    (b) fidelity of the reduced-precision path vs unquantised fp32 attention, its own stated tolerance:
+        cosine >= 0.995, rms error <= 8 % of the output rms (e4m3 carries 3 mantissa bits)."""
+    from hi3d_hip import ops
+    C = H * 64
+    qkv = rnd((B * S, 3 * C), 41)
+    qkv[:, :C] *= ops.Q_PRESCALE
+    qkv = bf(qkv)
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    att = lambda qq, kk: (torch.softmax((qq @ kk.transpose(-1, -2)) * math.log(2.0), dim=-1) @ v).transpose(1, 2).reshape(B * S, C)
+    ref_q, ref = att(_mx_e4m3(q), _mx_e4m3(k)), att(q, k)
+    out = ops.self_attention_fused_qkv_fp8qk(qkv.to(dev), B, S, H).float().cpu()
+    assert relerr(out, ref_q) < 2e-2
+    cos = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    rms = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"fp8-qk attention B{B} H{H} S{S}: vs quantised reference {relerr(out, ref_q):.4f}; vs fp32: cos {cos:.5f} rms {rms:.4f}")
+    assert cos > 0.995 and rms < 8e-2
+
+
 @pytest.mark.parametrize("case", ["huge_logits", "all_very_negative", "late_outlier_ragged", "rising_max", "first_tile_outlier"])
 def test_attention_d64_reference_point_edge_cases(dev, case):
     """The kernel's softmax does not track the true row maximum (it checks row sums and moves the

@@ -90,7 +90,7 @@ def _reference(dev):
     return x.cpu(), fx
 
 
-@pytest.mark.parametrize("world,cfg", [(2, 2), (2, 1), (4, 2)])
+@pytest.mark.parametrize("world,cfg", [(2, 1), (4, 2)])
 def test_clip_parallel_step_matches_single_gpu(dev, world, cfg):
     ref, fx = _reference(dev)
     mgr = mp.Manager()

@@ -252,3 +252,19 @@ def test_fused_graph_step_equals_generic_step(dev):
     assert rel < 2e-3
     rel, cos = stats(outs["1"], fx["output"])
     assert rel < 6e-2 and cos > 0.999
+
+
+def test_unet_fp8_qk_attention_path(dev, monkeypatch):
+    """BASELINE config 5 (fp8 MFMA attention + bf16 conv): the full-width UNet with every spatial attention's
+    score product on the e4m3 / MX-scaled matrix path.  Separately stated tolerance for this reduced-precision
+    option: output cosine >= 0.998 and max-abs error <= 8e-2 x max-abs reference (bf16 default: 0.9995 / 4e-2)."""
+    monkeypatch.setenv("HI3D_ATTN_FP8QK", "1")
+    fx = load("unet_s1_lat16")
+    m = build_unet(fx, dev)
+    assert m.runtime(dev).attn_fp8qk
+    i = {k: v.to(dev) for k, v in fx["inputs"].items()}
+    out = m(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
+            image_only_indicator=i["image_only_indicator"])
+    rel, cos = stats(out, fx["output"])
+    print(f"fp8-qk UNet: rel {rel:.4f} cos {cos:.6f}")
+    assert rel < 8e-2 and cos > 0.998
