@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   const int qt = lid % p.nqt, bh = lid / p.nqt;
   const int h = bh % p.H, b = bh / p.H;
 
-  const char* zero = (const char*)hi3d_zero_page;
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[row li][d = ks*16 + hi*8 ..+7]
   // of each of the wave's QB query blocks
   int qrow[QB]; bool qok[QB];
@@ -83,31 +82,36 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   const int lrow = lane >> 3, lslot = lane & 7;
   const char* kbase = p.k + ((long)b * p.Skv * p.ldk + h * 64) * 2;
   const char* vbase = p.vt + ((long)(b * p.H + h) * 64) * (long)p.ldvt * 2;
-  int k_r[2], k_c[2], v_c[2]; long v_off[2];
+  // buffer-addressed LDS-DMA (as in gemm.hip): one descriptor per operand based at this (b, h), a 32-bit
+  // per-lane byte offset fixed for the whole loop, a scalar offset walking the key tiles.  Key rows >= Skv lie
+  // beyond num_records and read as zeros (no per-lane select, no 64-bit per-lane pointers).
+#if __HIP_DEVICE_COMPILE__
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)kbase, 0, (int)min((long)0x7fffffff, ((long)p.Skv - 1) * p.ldk * 2 + 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0x7fffffff, 0x00020000);
+  int k_vo[2], v_vo[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (w * 2 + i) * 8 + lrow;               // LDS row 0..63
-    k_r[i] = r;
-    k_c[i] = lslot ^ ((swap_bits23(r & 31) >> 1) & 7);   // read by MFMA row swap(r)
-    v_c[i] = lslot ^ ((r >> 1) & 7);
-    v_off[i] = (long)r * p.ldvt * 2;
+    const int kc = lslot ^ ((swap_bits23(r & 31) >> 1) & 7);   // read by MFMA row swap(r)
+    const int vc = lslot ^ ((r >> 1) & 7);
+    k_vo[i] = r * p.ldk * 2 + kc * 16;
+    v_vo[i] = r * p.ldvt * 2 + vc * 16;
   }
   auto issue = [&](int j, int st) {
     char* sK = smem + st * ATT_STAGE;
     char* sV = sK + KV_TILE * 128;
     const int kv0 = j * KV_TILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kv = kv0 + k_r[i];
-      const char* src = kbase + ((long)kv * p.ldk + k_c[i] * 8) * 2;
-      lds_dma16(kv < p.Skv ? src : zero, sK + (w * 2 + i) * 1024);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (LDS_AS void*)(sK + (w * 2 + i) * 1024), 16, k_vo[i], kv0 * p.ldk * 2, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const char* src = vbase + v_off[i] + (long)(kv0 + v_c[i] * 8) * 2;   // padded to 64: always in range
-      lds_dma16(src, sV + (w * 2 + i) * 1024);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(sV + (w * 2 + i) * 1024), 16, v_vo[i], kv0 * 2, 0, 0);   // padded to 64: in range
   };
+#else
+  auto issue = [&](int, int) {};
+#endif
 
   // fragment read addresses: one LDS pointer per k-step (the XOR swizzle is lane-specific),
   // moved between the ring stages once per tile; key block / d block are ds_read offsets

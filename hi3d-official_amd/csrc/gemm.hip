@@ -524,7 +524,10 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     tile = (w160 <= w128) ? 160 : 128;
     if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile = t; }
   }
-  if (tile != 128 && tile != 160) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 128 or 160");
+  // N <= 32 (the 4-channel output convs: UNet out.2, VAE conv_out): a 128 x 32 tile -- those launches are all
+  // A stream (M = 0.5-1 M rows, K = 1152-2880) and a 128-column tile spent 97 % of its MFMAs and W traffic on padding
+  if (d->tile_n == 0 && d->N <= 32 && d->epi == HI3D_EPI_AFFINE && !getenv("HI3D_GEMM_NO_NARROW")) tile = 32;
+  if (tile != 128 && tile != 160 && tile != 32) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 32, 128 or 160");
   // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU (default: fastest at every
   // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
   // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU;
@@ -546,6 +549,16 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.nbn = (d->N + tile - 1) / tile;
   hipStream_t s = (hipStream_t)stream;
   if (tile == 320) return dispatch<4, 10, 2>(p, d->amode, d->epi, s);
+  if (tile == 32) {
+    if (d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: the 32-column tile has no GEGLU form");
+    p.nbm = (d->M + 127) / 128;
+    switch (d->amode) {
+      case HI3D_A_DENSE: return launch<2, 1, 2, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
+      case HI3D_A_CONV3X3: return d->up2x ? launch<2, 1, 2, A_CONV3X3_UP2X, HI3D_EPI_AFFINE>(p, s)
+                                           : launch<2, 1, 2, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
+      case HI3D_A_CONVT3: return launch<2, 1, 2, HI3D_A_CONVT3, HI3D_EPI_AFFINE>(p, s);
+    }
+  }
   if (tile == 160) {
     if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
     if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);

@@ -3,8 +3,6 @@ current HIP stream, every FLOP runs in libhi3d_hip.so.
 
 Activations: torch.bfloat16, channels-last tokens [frames, H*W, C] (contiguous).
 """
-import os
-
 import torch
 
 from . import lib as _l
@@ -209,28 +207,14 @@ def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
 _gn_ws = {}
 
 
-GN_SPLIT_BYTES = int(float(os.environ.get("HI3D_GN_SPLIT_MB", "0")) * (1 << 20))
-
-
 def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
     """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32).
-
-    The kernel reads x twice (statistics, then normalise).  With HI3D_GN_SPLIT_MB=<n> a tensor larger than n MiB
-    is processed in runs of whole instances of at most n MiB, so that the second read of a run still finds
-    it in the 256 MB Infinity Cache instead of going back to HBM (A/B switch, off by default)."""
+    (Tried, MI355X: processing runs of instances that fit the 256 MB Infinity Cache so that the second read of x
+    hits it -- 0.204 -> 0.236-0.248 ms at [32 x 16384 x 320]: the smaller grids cost more than the re-read.)"""
     _chk_dev(x, gamma, beta, out)
     assert x.is_contiguous() and x.numel() == inst * P * C
     if out is None:
         out = torch.empty_like(x)
-    per = P * C * 2
-    if GN_SPLIT_BYTES and inst > 1 and inst * per > GN_SPLIT_BYTES:
-        step = max(1, GN_SPLIT_BYTES // per)
-        if step < inst:
-            xv, ov = x.reshape(inst, P * C), out.reshape(inst, P * C)
-            for lo in range(0, inst, step):
-                n = min(step, inst - lo)
-                _groupnorm_silu(xv[lo:lo + n], gamma, beta, n, P, C, eps, silu, ov[lo:lo + n])
-            return out
     return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out)
 
 

@@ -1,28 +1,42 @@
 #!/bin/bash
-# Regenerates what profiles/ holds, on the GPU box (run through gpurun from the repo root):
-#   bench logs (stage 2 with CPU baseline, stage 1), rocprofv3 kernel trace summary, and the two PMC
-#   passes (FETCH_SIZE, WRITE_SIZE -- separate runs, kernel trace only, as the pool requires).
-# Outputs land in gpurun_out/final_*; copy them to profiles/ and rebuild profiles/traffic_s2.json with
-#   python tools/make_traffic_json.py gpurun_out/final_traffic_FETCH_SIZE.csv gpurun_out/final_traffic_WRITE_SIZE.csv profiles/traffic_s2.json
+# Regenerates what profiles/ holds for a round, on the GPU box (run through gpurun from the repo root):
+#   bench lines + per-shape logs (stage 2 with CPU baseline, stage 1, VAE decode, fp8-QK attention variant),
+#   rocprofv3 kernel-trace summary of the stage-2 bench, and PMC passes (separate runs, kernel trace only, as the
+#   pool requires): FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel) and two SQ passes (MFMA busy / VALU).
+# Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ (tools/collect_profiles.sh).
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py --config s2 > $O/final_s2_bench.log 2>&1
-python bench.py --config s1 --no-cpu-baseline > $O/final_s1_bench.log 2>&1
+python bench.py --config s2 --steps 10 --warmup 3 --shapes > $O/s2_bench.json 2> $O/s2_bench.log
+python bench.py --config s1 --steps 20 --warmup 3 --shapes --no-cpu-baseline > $O/s1_bench.json 2> $O/s1_bench.log
+python bench.py --config vae --steps 2 --warmup 1 > $O/vae_bench.json 2> $O/vae_bench.log
+python bench.py --config s2 --attn fp8qk --steps 6 --warmup 3 --no-cpu-baseline > $O/s2_fp8qk_bench.json 2> $O/s2_fp8qk_bench.log
 cd /tmp; export TMPDIR=/tmp
-rm -rf $O/prof_r01c
-rocprofv3 --kernel-trace --stats -d $O/prof_r01c -o s2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/final_s2_bench_under_rocprof.log 2>&1
-DB=$(ls $O/prof_r01c/*.db | head -1)
-python $R/tools/rocpd_summary.py $DB $O/final_s2_kernel_stats.csv 2> $O/final_s2_kernel_stats.txt
-rm -rf $O/prof_r01c
+rm -rf /tmp/prof_kt
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile > $O/s2_bench_under_rocprof.log 2>&1
+DB=$(ls /tmp/prof_kt/*.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats.csv 2> $O/s2_kernel_stats.txt
+rm -rf /tmp/prof_kt
+rocprofv3 -L > $O/rocprof_counters.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/final_pmc_$c.log 2>&1
-  python $R/tools/pmc_traffic.py /tmp/pmc_$c $c > $O/final_traffic_$c.csv
+  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_$c.log 2>&1
+  python $R/tools/pmc_traffic.py /tmp/pmc_$c $c > $O/s2_pmc_$c.csv
   rm -rf /tmp/pmc_$c
 done
-tail -1 $O/final_s2_bench.log | cut -c1-600
-tail -1 $O/final_s1_bench.log | cut -c1-300
-head -8 $O/final_s2_kernel_stats.csv
-head -6 $O/final_traffic_FETCH_SIZE.csv
-head -6 $O/final_traffic_WRITE_SIZE.csv
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"; do
+  i=$((i+1))
+  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_sq$i -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_sq$i.log 2>&1
+  python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.txt 2>&1
+  rm -rf /tmp/pmc_sq$i
+done
+cat $O/s2_bench.json | cut -c1-700
+cat $O/s1_bench.json | cut -c1-300
+cat $O/vae_bench.json | cut -c1-400
+cat $O/s2_fp8qk_bench.json | cut -c1-300
+head -12 $O/s2_kernel_stats.csv
+head -8 $O/s2_pmc_FETCH_SIZE.csv
+head -8 $O/s2_pmc_WRITE_SIZE.csv
+grep -i "gemm_bf16\|attn_d64" $O/s2_pmc_sq1.txt | head -12
