@@ -26,10 +26,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
 done
 i=0
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"; do
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   HI3D_STEP_GRAPH=0 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_sq$i -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_sq$i.log 2>&1
-  python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.txt 2>&1
+  python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.csv 2>&1
   rm -rf /tmp/pmc_sq$i
 done
 cat $O/s2_bench.json | cut -c1-700
@@ -39,4 +39,4 @@ cat $O/s2_fp8qk_bench.json | cut -c1-300
 head -12 $O/s2_kernel_stats.csv
 head -8 $O/s2_pmc_FETCH_SIZE.csv
 head -8 $O/s2_pmc_WRITE_SIZE.csv
-grep -i "gemm_bf16\|attn_d64" $O/s2_pmc_sq1.txt | head -12
+head -14 $O/s2_pmc_sq1.csv; head -8 $O/s2_pmc_sq2.csv
