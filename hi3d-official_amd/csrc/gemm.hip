@@ -40,7 +40,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // NS   : LDS ring stages.  NS = 2: loads of K-step k+1 fly during K-step k (vmcnt(0) per step).
 //        NS = 3: two K-steps in flight, counted vmcnt (the newest stage's LDS-DMA stays in
 //        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
-template <int WM, int NT, int NS, int AMODE_, int EPI>
+// PP   : "ping-pong" K loop (8-wave tiles only, see below): the two waves of a SIMD run half a phase apart, one in
+//        its MFMA segment while the other reads fragments / issues LDS-DMA.
+template <int WM, int NT, int NS, int AMODE_, int EPI, bool PP = false>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
@@ -146,7 +148,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
   int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
 
-  auto issue = [&](int kt, int st) {
+  // LDS-DMA pieces [LO, HI) of K chunk `kt` into ring slot `st`: pieces 0..3 are this wave's A rows, 4.. its W rows
+  // (the ping-pong loop spreads the pieces of a stage over its phases; the plain loops issue them all at once)
+  auto issue_pieces = [&](int kt, int st, auto lo_, auto hi_) {
+    constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
     unsigned soff;                                 // scalar byte offset of this K chunk
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     else soff = (tap * p.HW * p.Cin + c0) * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (i < LO || i >= HI) continue;
       unsigned vo = a_voff[i];
       if (AMODE == HI3D_A_CONV3X3 && UP2X) {
         const int iy = a_p0[i] + tap / 3 - 1, ix = a_p1[i] + tap % 3 - 1;   // on the virtual 2H x 2W grid
@@ -167,16 +173,23 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
+      if (4 + i < LO || 4 + i >= HI) continue;
       const int q = w + NW * i;
       if (q < 4 * NT)                               // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (LDS_AS void*)(sB + q * 1024), 16, b_voff[i],
                                                  AMODE == HI3D_A_DENSE ? kt * (BK * 2) : (tap * p.Cin + c0) * 2, 0, 0);
     }
-    // K walks the taps INNERMOST: the 9 (3) shifted reads of one 64-channel slab of the input happen in
-    // consecutive K steps, in every block of the wave front at about the same time, so a slab comes from
-    // HBM / the fabric once and the other taps hit L2.  (Round 1 walked taps outermost and re-fetched the
-    // input per tap: FETCH_SIZE 6.5x the algorithmic bytes.)
+  };
+  // K walks the taps INNERMOST: the 9 (3) shifted reads of one 64-channel slab of the input happen in
+  // consecutive K steps, in every block of the wave front at about the same time, so a slab comes from
+  // HBM / the fabric once and the other taps hit L2.  (Round 1 walked taps outermost and re-fetched the
+  // input per tap: FETCH_SIZE 6.5x the algorithmic bytes.)
+  auto advance_k = [&]() {
     if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) { tap = 0; c0 += BK; } }
+  };
+  auto issue = [&](int kt, int st) {
+    issue_pieces(kt, st, std::integral_constant<int, 0>{}, std::integral_constant<int, 4 + W_PIECES>{});
+    advance_k();
   };
 
   // ---- fragment read addresses (bytes within a stage)
@@ -291,68 +304,161 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
   const int nk = p.K / BK;
   const int pf_kt = nk >= 2 ? nk - 2 : 0;
-  if (NS != 1) issue(0, 0);
-  if (NS == 3 && nk > 1) issue(1, 1);
   int st = 0;
-  // one K step; `first` selects the C = 0 form of the MFMAs (saves zero-filling 16*NT registers)
-  auto kstep = [&](const int kt, auto first) {
-    constexpr bool FIRST = decltype(first)::value;
-    if (NS == 1) {
-      // single stage, 36-40 KiB LDS: 3 blocks per CU hide each other's loads and epilogues
-      if (kt) __syncthreads();                // everyone is done reading the stage
-      issue(kt, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    } else if (NS == 3) {
-      // stage kt must have landed; the LDS-DMA of stage kt+1 (>= LPS_MIN ops per wave) may stay in flight
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS_MIN) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();           // raw barrier: no implicit vmcnt(0) drain
-      if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                        // stage st landed; stage st^1 free again
-      if (kt + 1 < nk) issue(kt + 1, st ^ 1);
-    }
-    if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < VSLOT / 16) {   // both vector slots have landed: fold them
-      f32x4 b = *(const f32x4*)(vec_lds + tid * 16);            // (read again only after later barriers)
+  if constexpr (PP) {
+    // ---- ping-pong K loop (256-row tiles: 8 waves, two per SIMD, one block per CU).
+    // A K step is cut into phases of 4 x NTH MFMAs; every phase is
+    //     [load segment: LDS-DMA pieces of a later stage, ds_read of this phase's fragments, lgkmcnt(0)]
+    //     s_barrier  [compute segment: the MFMAs]  s_barrier
+    // and waves 4..7 (the second wave of each SIMD) pass one extra barrier before the loop (waves 0..3 pass it
+    // after), so the two waves of a SIMD are always in opposite segments: the matrix pipe of a SIMD sees one
+    // wave's MFMA cluster while the other waits for LDS -- in the lock-step loop both wait, then both compute.
+    // Ring protocol (D = NS-1 stages ahead; all waits counted, raw barriers, never vmcnt(0) in steady state):
+    //   WAR  pieces of stage kt+D overwrite the slot last read in step kt-1; those ds_reads were retired by the
+    //        lgkmcnt(0) that precedes the barrier ending the reader's load segment, and the earliest writer
+    //        (a wave of the leading half) issues one barrier later;
+    //   RAW  every wave waits for its own pieces of stage kt+1 (the D-1 newer stages may stay in flight) at the
+    //        end of the LAST load segment of step kt; the trailing half does so one barrier before the leading
+    //        half's first read of stage kt+1.
+    static_assert(WM == 4 && NS >= 2 && NS <= 3, "ping-pong K loop: 8 waves, ring of 2 or 3 stages");
+    constexpr int D = NS - 1;
+    constexpr int NTH = (NT > 5) ? NT / 2 : NT;   // weight fragments per phase
+    constexpr int NHALF = NT / NTH;
+    constexpr int NPH = 2 * NHALF;                // phases per K step
+    constexpr int NISS = (D == 1) ? NPH - 1 : NPH;   // phases that issue LDS-DMA (ring of 2: none in the phase that waits)
+    constexpr int TP = 4 + W_PIECES;              // LDS-DMA pieces per wave and stage
+    const bool late = w >= 4;
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < nk) issue(d, d);
+    if (D > 1 && nk >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS_MIN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS for everyone
+    if (EPI == HI3D_EPI_AFFINE && tid < VSLOT / 16) {   // so are both vector slots (requested before stage 0): fold them
+      f32x4 b = *(const f32x4*)(vec_lds + tid * 16);    // (here, not inside the loop: there it cost 40 registers)
       const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
       b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
       *(f32x4*)(vec_lds + tid * 16) = b;
     }
-    if (EPI == HI3D_EPI_AFFINE && NT <= 5 && p.R1 && kt == pf_kt) {
-#pragma unroll
-      for (int pass = 0; pass < RP; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
-    }
-    const char* s = smem + st * STAGE;
-    __builtin_amdgcn_s_setprio(1);   // MFMA cluster first: measured +0.4 % on the dense shapes (hurts in attention)
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      constexpr int NTH = (NT > 5) ? NT / 2 : NT;   // weight fragments held at a time
+    if (late) __builtin_amdgcn_s_barrier();       // the stagger
+    auto kstep_pp = [&](const int kt, auto first) {
+      constexpr bool FIRST = decltype(first)::value;
+      const char* s = smem + st * STAGE;
+      const int st_pf = st == 0 ? NS - 1 : st - 1;  // ring slot of stage kt + D
+      const bool pf = kt + D < nk;
       bf16x8 xf[4];
-      const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
-      const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
+      for (int ph = 0; ph < NPH; ++ph) {
+        const int kh = ph / NHALF, nh = ph % NHALF;
+        const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
+        const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
+        // ---- load segment
+        if (ph < NISS && pf) {
+          if (ph == 0) issue_pieces(kt + D, st_pf, std::integral_constant<int, 0>{}, std::integral_constant<int, TP / NISS>{});
+          if (ph == 1) issue_pieces(kt + D, st_pf, std::integral_constant<int, TP / NISS>{}, std::integral_constant<int, (NISS == 2) ? TP : 2 * TP / NISS>{});
+          if (ph == 2) issue_pieces(kt + D, st_pf, std::integral_constant<int, 2 * TP / NISS>{}, std::integral_constant<int, (NISS == 3) ? TP : 3 * TP / NISS>{});
+          if (ph == 3) issue_pieces(kt + D, st_pf, std::integral_constant<int, 3 * TP / NISS>{}, std::integral_constant<int, TP>{});
+          if (ph == NISS - 1) advance_k();
+        }
+        if (ph == 0 && EPI == HI3D_EPI_AFFINE && NT <= 5 && p.R1 && kt == pf_kt) {
 #pragma unroll
-      for (int nh = 0; nh < NT / NTH; ++nh) {
+          for (int pass = 0; pass < RP; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
+        }
         bf16x8 wf[NTH];
+        if (nh == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
+        }
 #pragma unroll
         for (int nt = 0; nt < NTH; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nh * NTH + nt] + cw);
+        if (ph == NPH - 1) {                        // stage kt+1 (own pieces) has landed
+          if (D > 1 && pf) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS_MIN) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute segment
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTH; ++nt)
             acc[mt][nh * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 wf[nt], xf[mt], (FIRST && PEEL0 && kh == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mt][nh * NTH + nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (NS == 3) st = (st == 2) ? 0 : st + 1;
-    else if (NS == 2) st ^= 1;
-  };
-  if (PEEL0) kstep(0, std::true_type{});
-  for (int kt = PEEL0 ? 1 : 0; kt < nk; ++kt) kstep(kt, std::false_type{});
+      st = (st + 1 == NS) ? 0 : st + 1;
+    };
+    if (PEEL0) kstep_pp(0, std::true_type{});
+    for (int kt = PEEL0 ? 1 : 0; kt < nk; ++kt) kstep_pp(kt, std::false_type{});
+    if (!late) __builtin_amdgcn_s_barrier();      // the leading half catches the stagger up
+  } else {
+    if (NS != 1) issue(0, 0);
+    if (NS == 3 && nk > 1) issue(1, 1);
+    // one K step; `first` selects the C = 0 form of the MFMAs (saves zero-filling 16*NT registers)
+    auto kstep = [&](const int kt, auto first) {
+      constexpr bool FIRST = decltype(first)::value;
+      if (NS == 1) {
+        // single stage, 36-40 KiB LDS: 3 blocks per CU hide each other's loads and epilogues
+        if (kt) __syncthreads();                // everyone is done reading the stage
+        issue(kt, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else if (NS == 3) {
+        // stage kt must have landed; the LDS-DMA of stage kt+1 (>= LPS_MIN ops per wave) may stay in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // raw barrier: no implicit vmcnt(0) drain
+        if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // stage st landed; stage st^1 free again
+        if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+      }
+      if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < VSLOT / 16) {   // both vector slots have landed: fold them
+        f32x4 b = *(const f32x4*)(vec_lds + tid * 16);            // (read again only after later barriers)
+        const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
+        b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
+        *(f32x4*)(vec_lds + tid * 16) = b;
+      }
+      if (EPI == HI3D_EPI_AFFINE && NT <= 5 && p.R1 && kt == pf_kt) {
+  #pragma unroll
+        for (int pass = 0; pass < RP; ++pass) fetch_residual(p.R1, p.ldr1, pass, r1v[pass]);
+      }
+      const char* s = smem + st * STAGE;
+      __builtin_amdgcn_s_setprio(1);   // MFMA cluster first: measured +0.4 % on the dense shapes (hurts in attention)
+  #pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        constexpr int NTH = (NT > 5) ? NT / 2 : NT;   // weight fragments held at a time
+        bf16x8 xf[4];
+        const int cx = ((kh * 4 + fg) ^ x_sw) << 4;
+        const int cw = ((kh * 4 + fg) ^ w_sw) << 4;
+  #pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(s + x_off[mt] + cx);
+  #pragma unroll
+        for (int nh = 0; nh < NT / NTH; ++nh) {
+          bf16x8 wf[NTH];
+  #pragma unroll
+          for (int nt = 0; nt < NTH; ++nt) wf[nt] = *(const bf16x8*)(s + w_off[nh * NTH + nt] + cw);
+  #pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+  #pragma unroll
+            for (int nt = 0; nt < NTH; ++nt)
+              acc[mt][nh * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  wf[nt], xf[mt], (FIRST && PEEL0 && kh == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mt][nh * NTH + nt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (NS == 3) st = (st == 2) ? 0 : st + 1;
+      else if (NS == 2) st ^= 1;
+    };
+    if (PEEL0) kstep(0, std::true_type{});
+    for (int kt = PEEL0 ? 1 : 0; kt < nk; ++kt) kstep(kt, std::false_type{});
+  }
   if (PRECHUNK && NT > 5) init_chunks();
 
   // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
@@ -448,27 +554,27 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 #endif
 }
 
-template <int WM, int NT, int NS, int AMODE, int EPI>
+template <int WM, int NT, int NS, int AMODE, int EPI, bool PP = false>
 int launch(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2 * ((32 * NT * 4 + 1023) / 1024 * 1024);   // ring + bias / row-vector slots
   static bool attr_done[HI3D_MAX_DEVICES] = {};
-  if (int rc = hi3d_raise_lds_limit((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>, smem, attr_done)) return rc;
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI>), dim3(p.nbm * p.nbn), dim3(WM * 128), smem, stream, p);
+  if (int rc = hi3d_raise_lds_limit((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>, smem, attr_done)) return rc;
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>), dim3(p.nbm * p.nbn), dim3(WM * 128), smem, stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }
 
-template <int WM, int NT, int NS>
+template <int WM, int NT, int NS, bool PP = false>
 int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
   if (epi == HI3D_EPI_GEGLU) {
     if (amode != HI3D_A_DENSE) HI3D_FAIL(HI3D_ESHAPE, "gemm: GEGLU epilogue only with dense A");
-    return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_GEGLU>(p, s);
+    return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_GEGLU, PP>(p, s);
   }
   switch (amode) {
-    case HI3D_A_DENSE: return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
-    case HI3D_A_CONV3X3: return p.up2x ? launch<WM, NT, NS, A_CONV3X3_UP2X, HI3D_EPI_AFFINE>(p, s)
-                                        : launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE>(p, s);
-    case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE>(p, s);
+    case HI3D_A_DENSE: return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_AFFINE, PP>(p, s);
+    case HI3D_A_CONV3X3: return p.up2x ? launch<WM, NT, NS, A_CONV3X3_UP2X, HI3D_EPI_AFFINE, PP>(p, s)
+                                        : launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE, PP>(p, s);
+    case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE, PP>(p, s);
   }
   HI3D_FAIL(HI3D_EINVAL, "gemm: bad amode");
 }
@@ -543,12 +649,13 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
   }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
-  if (variant == 5) tile = 320;             // 256 x 320 tile: 8 waves of 64 x 160, one block per CU
-  const int bm = (variant == 2 || variant == 5) ? 256 : 128;
+  // 6 = 256-row tile (x 128 / 160), 3-stage ring, ping-pong K loop; 7 = 256 x 320 tile, 2-stage ring, ping-pong K loop
+  if (variant == 5 || variant == 7) tile = 320;   // 256 x 320 tile: 8 waves of 64 x 160, one block per CU
+  const int bm = (variant == 2 || variant == 5 || variant == 6 || variant == 7) ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
   hipStream_t s = (hipStream_t)stream;
-  if (tile == 320) return dispatch<4, 10, 2>(p, d->amode, d->epi, s);
+  if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);
   if (tile == 32) {
     if (d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: the 32-column tile has no GEGLU form");
     p.nbm = (d->M + 127) / 128;
@@ -560,11 +667,13 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     }
   }
   if (tile == 160) {
+    if (variant == 6) return dispatch<4, 5, 3, true>(p, d->amode, d->epi, s);
     if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
     if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);
     if (variant == 3) return dispatch<2, 5, 1>(p, d->amode, d->epi, s);
     return dispatch<2, 5, 2>(p, d->amode, d->epi, s);
   }
+  if (variant == 6) return dispatch<4, 4, 3, true>(p, d->amode, d->epi, s);
   if (variant == 2) return dispatch<4, 4, 3>(p, d->amode, d->epi, s);
   if (variant == 1) return dispatch<2, 4, 3>(p, d->amode, d->epi, s);
   if (variant == 3) return dispatch<2, 4, 1>(p, d->amode, d->epi, s);

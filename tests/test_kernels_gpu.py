@@ -72,10 +72,11 @@ def test_gemm_geglu(dev, M, Nh, K):
     assert relerr(out, ref) < BF16_TOL
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7])
 def test_gemm_tile_variants(dev, variant, monkeypatch):
     """The tile variants the host heuristic picks only for large shapes (256-row tiles, single-stage
-    ring, 256 x 320 tile) forced onto small ragged shapes: every epilogue, conv gather and GEGLU."""
+    ring, 256 x 320 tile, the ping-pong K loops 6 / 7) forced onto small ragged shapes: every epilogue,
+    conv gather and GEGLU."""
     from hi3d_hip import ops
     monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
     M, N, K, rpg = 700, 640, 320, 256            # rpg multiple of the 256-row tile and not (M tail)
@@ -104,6 +105,47 @@ def test_gemm_tile_variants(dev, variant, monkeypatch):
     outc = ops.gemm(xt.to(dev), pack_conv3x3(wc, Cin).to(dev), M=Fr * H * Wd, N=Cout, K=9 * Cin, bias=bc.to(dev),
                     conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0))
     assert relerr(outc, refc) < BF16_TOL
+
+
+@pytest.mark.parametrize("variant", [6, 7])
+def test_gemm_pingpong_long_k_race_screen(dev, variant, monkeypatch):
+    """The ping-pong K loops (staggered wave halves, counted vmcnt, LDS ring re-used every 2-3 K steps) on a
+    grid that fills the chip, K long enough to wrap the ring many times: dense with residual, Conv3d (3,1,1)
+    and a strided conv3x3, each run several times -- results must match the fp32 reference AND be bit-identical
+    between runs (an LDS-DMA race shows up as run-to-run differences long before it shows up as a large error)."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
+    M, N, K = 256 * 300 + 72, 640, 2560
+    A, W = bf(rnd((M, K), 41)), bf(rnd((N, K), 42, K ** -0.5))
+    bias, R1 = rnd((N,), 43), bf(rnd((M, N), 44))
+    Ad, Wd, bd, Rd = A.to(dev), W.to(dev), bias.to(dev), R1.to(dev)
+    outs = [ops.gemm(Ad, Wd, M=M, N=N, K=K, bias=bd, R1=Rd) for _ in range(4)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    rows = torch.cat([torch.arange(0, 600), torch.arange(M - 600, M), torch.randint(0, M, (800,), generator=torch.Generator().manual_seed(5))])
+    ref = A[rows].float() @ W.float().T + bias + R1[rows].float()
+    assert relerr(outs[0][rows.to(dev)], ref) < BF16_TOL
+    # Conv3d (3,1,1): T = 5 frames of 40 x 40 pixels, 2 clips, C = 320
+    from hi3d_hip.pack import pack_convt3
+    B, T, HW, C = 2, 5, 1600, 320
+    x = bf(rnd((B, C, T, HW, 1), 45))
+    wt = bf(rnd((C, C, 3, 1, 1), 46, (3 * C) ** -0.5)).float()
+    reft = F.conv3d(x.float(), wt, None, padding=(1, 0, 0))               # b c t hw 1
+    xt = x.squeeze(-1).permute(0, 2, 3, 1).contiguous().reshape(-1, C)    # (b t hw) c
+    ot = [ops.gemm(xt.to(dev), pack_convt3(wt).to(dev), M=B * T * HW, N=C, K=3 * C, convt3=dict(T=T, HW=HW, Cin=C)) for _ in range(3)]
+    assert torch.equal(ot[0], ot[1]) and torch.equal(ot[0], ot[2])
+    assert relerr(ot[0].float().cpu().reshape(B, T, HW, C).permute(0, 3, 1, 2).unsqueeze(-1), reft) < BF16_TOL
+    # conv3x3 stride 2 (Downsample): 6 frames 64 x 48 -> 32 x 24, Cin 128 -> Cout 320
+    Fr, H, Wd_, Cin, Cout = 6, 64, 48, 128, 320
+    xc, wc, bc = bf(rnd((Fr, Cin, H, Wd_), 47)), bf(rnd((Cout, Cin, 3, 3), 48, (9 * Cin) ** -0.5)).float(), rnd((Cout,), 49)
+    refc = F.conv2d(xc.float(), wc, bc, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xct = xc.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin)
+    oc = [ops.gemm(xct.to(dev), pack_conv3x3(wc, Cin).to(dev), M=Fr * (H // 2) * (Wd_ // 2), N=Cout, K=9 * Cin, bias=bc.to(dev),
+                   conv3x3=dict(Hin=H, Win=Wd_, Cin=Cin, Hout=H // 2, Wout=Wd_ // 2, stride=2, up2x=0)) for _ in range(3)]
+    assert torch.equal(oc[0], oc[1]) and torch.equal(oc[0], oc[2])
+    assert relerr(oc[0], refc) < BF16_TOL
 
 
 @pytest.mark.parametrize("M,blend", [(300, False), (1000, True), (128, False)])

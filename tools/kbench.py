@@ -102,7 +102,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -168,3 +168,81 @@ def bench_ffn():
 
 if len(sys.argv) > 1 and sys.argv[1] == "ffn":
     bench_ffn()
+
+
+def bench_sweep():
+    """kbench.py sweep [variants...] : every GEMM / conv shape of the stage-2 step (and the VAE decoder's convs)
+    timed under each HI3D_GEMM_VARIANT (default: the host heuristic 'h', 0, 2, 6, 7; GEGLU also 3, 5), same
+    buffers, interleaved rounds -- the table the dispatch heuristic in csrc/gemm.hip is set from."""
+    variants = sys.argv[2:] or ["h", "0", "2", "6", "7"]
+    dense = [  # (M, N, K, kind)
+        (131072, 5120, 640, "geglu"), (32768, 10240, 1280, "geglu"), (8192, 10240, 1280, "geglu"),
+        (524288, 960, 320, "plain"), (131072, 1920, 640, "plain"), (32768, 3840, 1280, "plain"),
+        (524288, 320, 320, "res"), (131072, 640, 640, "res"), (32768, 1280, 1280, "res"),
+        (131072, 640, 2560, "res"), (32768, 1280, 5120, "res"), (8192, 1280, 5120, "res"),
+        (524288, 320, 960, "res"), (131072, 640, 1920, "res"), (32768, 1280, 2560, "res"),   # skip_connection 1x1
+        (1048576, 128, 256, "plain"), (16384, 16384, 512, "plain"),                          # VAE nin_shortcut, q k^T
+    ]
+    conv = [  # (frames, Hin, Cin, Cout, stride, up2x, res)
+        (32, 128, 320, 320, 1, 0, True), (32, 128, 640, 320, 1, 0, False), (32, 128, 960, 320, 1, 0, False),
+        (32, 64, 640, 640, 1, 0, True), (32, 64, 1280, 640, 1, 0, False), (32, 64, 1920, 640, 1, 0, False),
+        (32, 32, 1280, 1280, 1, 0, True), (32, 32, 2560, 1280, 1, 0, False), (32, 16, 1280, 1280, 1, 0, True),
+        (32, 128, 320, 320, 2, 0, False), (32, 64, 640, 640, 1, 1, False), (32, 32, 1280, 1280, 1, 1, False),
+        (1, 1024, 128, 128, 1, 0, True), (1, 512, 256, 256, 1, 0, True), (1, 256, 512, 512, 1, 0, True),
+        (1, 128, 512, 512, 1, 0, True), (1, 512, 256, 256, 1, 1, False), (1, 1024, 256, 128, 1, 0, False),
+    ]
+    convt = [(128, 320), (64, 640), (32, 1280)]
+
+    def run(label, fl, fn, vs):
+        best = {}
+        for rnd_ in range(2):
+            for v in vs:
+                if v == "h":
+                    os.environ.pop("HI3D_GEMM_VARIANT", None)
+                else:
+                    os.environ["HI3D_GEMM_VARIANT"] = v
+                try:
+                    ms = timeit(fn, iters=4, warm=1)
+                except Exception as e:  # noqa: BLE001
+                    ms = float("nan")
+                best[v] = min(best.get(v, 1e9), ms)
+        os.environ.pop("HI3D_GEMM_VARIANT", None)
+        cells = "  ".join(f"{v}:{best[v]:7.3f}ms {fl / best[v] / 1e9:6.0f}TF" for v in vs)
+        print(f"  {label:52s} {cells}", flush=True)
+
+    print("== dense")
+    for M, N, K, kind in dense:
+        A, W = rb(M, K), rb(N, K)
+        bias = torch.randn(N, device=dev)
+        geglu = kind == "geglu"
+        R1 = rb(M, N) if kind == "res" else None
+        out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.bfloat16)
+        vs = variants + (["3", "5"] if geglu and not sys.argv[2:] else [])
+        run(f"dense M={M} N={N} K={K} {kind}", 2.0 * M * N * K,
+            lambda: ops.gemm(A, W, M=M, N=N, K=K, bias=bias, R1=R1, geglu=geglu, out=out), vs)
+        del A, W, out, R1
+    print("== conv3x3")
+    for Fr, H, Cin, Cout, stride, up, res in conv:
+        Ho = H * 2 if up else H // stride
+        M, K = Fr * Ho * Ho, 9 * Cin
+        A, W = rb(Fr * H * H, Cin), rb(Cout, K)
+        bias = torch.randn(Cout, device=dev)
+        R1 = rb(M, Cout) if res else None
+        out = torch.empty((M, Cout), device=dev, dtype=torch.bfloat16)
+        geo = dict(Hin=H, Win=H, Cin=Cin, Hout=Ho, Wout=Ho, stride=stride, up2x=up)
+        run(f"conv F={Fr} {H}->{Ho} {Cin}->{Cout}{' +R1' if res else ''}", 2.0 * M * Cout * K,
+            lambda: ops.gemm(A, W, M=M, N=Cout, K=K, bias=bias, R1=R1, conv3x3=geo, out=out), variants)
+        del A, W, out, R1
+    print("== conv temporal")
+    for H, C in convt:
+        M, K = 32 * H * H, 3 * C
+        A, W, R2 = rb(M, C), rb(C, K), rb(M, C)
+        bias = torch.randn(C, device=dev)
+        out = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
+        run(f"convt H={H} C={C} +R2", 2.0 * M * C * K,
+            lambda: ops.gemm(A, W, M=M, N=C, K=K, bias=bias, R2=R2, convt3=dict(T=16, HW=H * H, Cin=C), out=out), variants)
+        del A, W, out, R2
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    bench_sweep()
