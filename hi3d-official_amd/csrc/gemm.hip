@@ -643,18 +643,34 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // K is short, and 12-16 % from the 256 x 320 tile (variant 5) at K >= 640; plain GEMMs gain
   // 3-7 % from the 256-row tile when both K and N are long; everything else, and every conv,
   // is fastest at 0.
+  // 7 = 256 x 320 tile with the ping-pong K loop (2-stage ring), 8 = the same at 256 x 256 (N multiples of 256: the
+  // VAE), 6 = 256 x 128 / 160 ping-pong, 3-stage ring (never the fastest; kept for A/B).  Measured (kbench.py
+  // sweep, profiles/r02b_gemm_variant_sweep.log): the ping-pong wide tile wins +10-13 % on every conv3x3 /
+  // strided / 2x-upsampling conv, +15-24 % on the QKV projections, +8-20 % on dense GEMMs with K >= 1920, as long
+  // as the grid still has >= 1 tile per CU; it loses on N = 320 / 640 with short K (one or two column tiles: the
+  // 128-row tile's second block per CU matters more) and below 256 tiles (the 16^2 level, M = 8192).
   int variant = 0;
+  auto wide_fits = [&](int tn) {          // >= 256 tiles of 256 x tn and <= 7 % of the columns wasted
+    const long nbn = (d->N + tn - 1) / tn;
+    return d->tile_n == 0 && d->N >= tn && nbn * tn * 100 <= (long)d->N * 107 && ((long)(d->M + 255) / 256) * nbn >= 256;
+  };
   if (d->amode == HI3D_A_DENSE) {
     if (d->epi == HI3D_EPI_GEGLU) variant = (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);
+    else if (wide_fits(320) && (d->N >= 960 || d->K >= 1920)) variant = 7;
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
+  } else if (wide_fits(320)) {
+    variant = 7;
+  } else if (d->N % 256 == 0 && wide_fits(256)) {
+    variant = 8;
   }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
-  // 6 = 256-row tile (x 128 / 160), 3-stage ring, ping-pong K loop; 7 = 256 x 320 tile, 2-stage ring, ping-pong K loop
   if (variant == 5 || variant == 7) tile = 320;   // 256 x 320 tile: 8 waves of 64 x 160, one block per CU
-  const int bm = (variant == 2 || variant == 5 || variant == 6 || variant == 7) ? 256 : 128;
+  if (variant == 8) tile = 256;                   // 256 x 256 tile: 8 waves of 64 x 128
+  const int bm = (variant == 2 || variant >= 5) ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
   hipStream_t s = (hipStream_t)stream;
+  if (tile == 256) return dispatch<4, 8, 2, true>(p, d->amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);
   if (tile == 32) {
     if (d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: the 32-column tile has no GEGLU form");

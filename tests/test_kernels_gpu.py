@@ -72,7 +72,7 @@ def test_gemm_geglu(dev, M, Nh, K):
     assert relerr(out, ref) < BF16_TOL
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7, 8])
 def test_gemm_tile_variants(dev, variant, monkeypatch):
     """The tile variants the host heuristic picks only for large shapes (256-row tiles, single-stage
     ring, 256 x 320 tile, the ping-pong K loops 6 / 7) forced onto small ragged shapes: every epilogue,
@@ -107,7 +107,7 @@ def test_gemm_tile_variants(dev, variant, monkeypatch):
     assert relerr(outc, refc) < BF16_TOL
 
 
-@pytest.mark.parametrize("variant", [6, 7])
+@pytest.mark.parametrize("variant", [6, 7, 8])
 def test_gemm_pingpong_long_k_race_screen(dev, variant, monkeypatch):
     """The ping-pong K loops (staggered wave halves, counted vmcnt, LDS ring re-used every 2-3 K steps) on a
     grid that fills the chip, K long enough to wrap the ring many times: dense with residual, Conv3d (3,1,1)
