@@ -457,6 +457,14 @@ extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void*
   return HI3D_OK;
 }
 
+// debug aid: resident blocks per CU the runtime predicts for the spatial attention kernels (0: pre-scaled q, 1: scaled)
+extern "C" int hi3d_debug_attn_occupancy(int which) {
+  int n = -1;
+  if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<true>, 256, 0);
+  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<false>, 256, 0);
+  return n;
+}
+
 extern "C" int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
                                 int32_t S_pad, int32_t ldv, void* stream) {
   if (!v || !vt) HI3D_FAIL(HI3D_EINVAL, "transpose_v: null pointer");

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
     for (int i = 0; i < CH; ++i) dst[i] = fetch_chunk(R, ldr, pass, i);
   };
-  // The wide tile (NT > 5) has 160 accumulator registers and none to park residual slabs in:
-  // it loads each residual chunk where it is consumed (latency exposed; its K loops are long).
+  // The wide tile (NT > 5) has 160 accumulator registers and none to park residual slabs in during the K loop:
+  // it requests them one store pass ahead in the epilogue (below).
   constexpr bool RES_EARLY = NT <= 5;
 
   const int nk = p.K / BK;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         __syncthreads();                        // stage st landed; stage st^1 free again
         if (kt + 1 < nk) issue(kt + 1, st ^ 1);
       }
-      if (EPI == HI3D_EPI_AFFINE && kt == 0 && tid < VSLOT / 16) {   // both vector slots have landed: fold them
+      if (EPI == HI3D_EPI_AFFINE && NT <= 5 && kt == 0 && tid < VSLOT / 16) {   // both vector slots have landed: fold them
         f32x4 b = *(const f32x4*)(vec_lds + tid * 16);            // (read again only after later barriers)
         const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
         b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
@@ -459,6 +459,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     if (PEEL0) kstep(0, std::true_type{});
     for (int kt = PEEL0 ? 1 : 0; kt < nk; ++kt) kstep(kt, std::false_type{});
   }
+  if (!PP && NT > 5 && EPI == HI3D_EPI_AFFINE && tid < VSLOT / 16) {   // wide tile: the fold inside the loop cost it 40 registers (spills)
+    f32x4 b = *(const f32x4*)(vec_lds + tid * 16);                     // (slots landed before the first K step; read after the barrier below)
+    const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
+    b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
+    *(f32x4*)(vec_lds + tid * 16) = b;
+  }
   if (PRECHUNK && NT > 5) init_chunks();
 
   // ---- epilogue.  The MFMA C layout gives a lane 4 columns of 16 different rows: stored
@@ -467,6 +473,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // ring is free now), NPASS slabs of HR rows, and all global traffic (residual loads,
   // stores) is issued row-contiguous, 16 bytes per lane.
   if (EPI == HI3D_EPI_AFFINE && RES_EARLY && p.R2) fetch_residual(p.R2, p.ldr2, 0, r2v);
+  // wide tile: residual slabs one store pass ahead, in two alternating register sets (the accumulator blocks
+  // already staged free the registers); pass 0 is requested together with pass 1, once the first accumulator block
+  // is in LDS (earlier, its registers would spill), and is the only one whose latency is exposed
+  u32x4 rw1[2][CH];   // (R1 only: a second pair of sets for R2 spills; R2 -- AlphaBlender tails -- stays a load at the point of use)
   const int osz = p.out_fp32 ? 4 : 2;
   const __amdgpu_buffer_rsrc_t rsO =
       __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
@@ -491,6 +501,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           *(f32x4*)(trow + cl * 4) = v;
         }
       }
+    }
+    if (EPI == HI3D_EPI_AFFINE && !RES_EARLY) {
+      __builtin_amdgcn_sched_barrier(0);           // not before the accumulator block above has left its registers
+      if (half == 0 && p.R1) fetch_residual(p.R1, p.ldr1, 0, rw1[0]);
+      if (half + 1 < NPASS && p.R1) fetch_residual(p.R1, p.ldr1, half + 1, rw1[(half + 1) & 1]);
     }
     __syncthreads();
 #pragma unroll
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           if (has8) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
         }
         if (p.R1) {
-          const u32x4 r = RES_EARLY ? r1v[half % RP][i] : fetch_chunk(p.R1, p.ldr1, half, i);
+          const u32x4 r = RES_EARLY ? r1v[half % RP][i] : rw1[half & 1][i];
           v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
           v[4] += bf16_to_f32(r[2] & 0xffff); v[5] += bf16_to_f32(r[2] >> 16); v[6] += bf16_to_f32(r[3] & 0xffff); v[7] += bf16_to_f32(r[3] >> 16);
         }
@@ -647,8 +662,8 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // VAE), 6 = 256 x 128 / 160 ping-pong, 3-stage ring (never the fastest; kept for A/B).  Measured (kbench.py
   // sweep, profiles/r02b_gemm_variant_sweep.log): the ping-pong wide tile wins +10-13 % on every conv3x3 /
   // strided / 2x-upsampling conv, +15-24 % on the QKV projections, +8-20 % on dense GEMMs with K >= 1920, as long
-  // as the grid still has >= 1 tile per CU; it loses on N = 320 / 640 with short K (one or two column tiles: the
-  // 128-row tile's second block per CU matters more) and below 256 tiles (the 16^2 level, M = 8192).
+  // as the grid still has >= 1 tile per CU; it loses below 256 tiles (the 16^2 level, M = 8192) and on N that is
+  // not close to a multiple of 320 (the VAE's 128 / 256 / 512 channels).
   int variant = 0;
   auto wide_fits = [&](int tn) {          // >= 256 tiles of 256 x tn and <= 7 % of the columns wasted
     const long nbn = (d->N + tn - 1) / tn;
@@ -656,7 +671,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   };
   if (d->amode == HI3D_A_DENSE) {
     if (d->epi == HI3D_EPI_GEGLU) variant = (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);
-    else if (wide_fits(320) && (d->N >= 960 || d->K >= 1920)) variant = 7;
+    else if (wide_fits(320)) variant = 7;       // (since the residual slabs are requested a store pass ahead: also N = 320 / 640 with short K)
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
   } else if (wide_fits(320)) {
     variant = 7;

@@ -119,6 +119,8 @@ def bench_one():
     """kbench.py one <kind> M N K : a single GEMM shape, few iterations (for rocprofv3 --pmc)."""
     kind, M, N, K = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     A, W = rb(M, K), rb(N, K)
+    if len(sys.argv) > 6 and sys.argv[6] == "zero":      # power probe
+        A.zero_(); W.zero_()
     bias = torch.randn(N, device=dev)
     geglu = kind == "geglu"
     R1 = rb(M, N) if kind == "res" else None
@@ -136,10 +138,17 @@ def bench_attn_one():
     B, H, S = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     C = H * 64
     qkv = rb(B * S, 3 * C)
+    pre = len(sys.argv) > 5 and sys.argv[5] in ("pre", "zero", "const")     # the UNet's form: scale * log2(e) folded into q, scale argument 0
+    if pre:
+        qkv[:, :C] *= 0.125 * 1.4426950408889634
+    if len(sys.argv) > 5 and sys.argv[5] == "zero":      # power probe: no operand toggling at all
+        qkv.zero_()
+    if len(sys.argv) > 5 and sys.argv[5] == "const":     # power probe: every element the same value
+        qkv.fill_(0.25)
     vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
     out = torch.empty((B * S, C), device=dev, dtype=torch.bfloat16)
-    ms = timeit(lambda: ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, 0.125, out=out), iters=3, warm=1)
-    print(f"attn B={B} H={H} S={S}: {ms:.3f} ms {4.0 * B * H * S * S * 64 / ms / 1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, 0.0 if pre else 0.125, out=out), iters=3, warm=1)
+    print(f"attn B={B} H={H} S={S}{' pre-scaled q' if pre else ''}: {ms:.3f} ms {4.0 * B * H * S * S * 64 / ms / 1e9:.1f} TFLOP/s")
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "attn1":
@@ -182,6 +191,7 @@ def bench_sweep():
         (131072, 640, 2560, "res"), (32768, 1280, 5120, "res"), (8192, 1280, 5120, "res"),
         (524288, 320, 960, "res"), (131072, 640, 1920, "res"), (32768, 1280, 2560, "res"),   # skip_connection 1x1
         (1048576, 128, 256, "plain"), (16384, 16384, 512, "plain"),                          # VAE nin_shortcut, q k^T
+        (524288, 2560, 320, "geglu"), (524288, 320, 1280, "res"),                            # the two GEMMs the fused FFN replaces
     ]
     conv = [  # (frames, Hin, Cin, Cout, stride, up2x, res)
         (32, 128, 320, 320, 1, 0, True), (32, 128, 640, 320, 1, 0, False), (32, 128, 960, 320, 1, 0, False),
