@@ -28,6 +28,7 @@ struct GemmParams {
   int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8;
   int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW, pad;
   int nbm, nbn;
+  int abl;     // timing ablations (HI3D_GEMM_ABL; wrong results by design): 1 = output stores dropped, 2 = no epilogue at all
 };
 
 constexpr int BK = 64;
@@ -206,7 +207,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 
   f32x4 acc[4][NT];                                // first written by the MFMAs of K step 0 (C = 0)
   constexpr bool PEEL0 = NT <= 5 && AMODE == HI3D_A_DENSE;   // (wide tile, conv gathers: zero-fill instead -- peeling costs them registers / time)
-  if (!PEEL0) {
+  // wide ping-pong tiles: the accumulators START at bias (+ the tile's row vector) -- 160 moves once per tile instead
+  // of 320 adds and 40 LDS reads per wave in the epilogue, which is VALU-bound there (set below, once the vectors landed)
+  constexpr bool BIAS_INIT = PP && NT > 5;
+  if (!PEEL0 && !BIAS_INIT) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -333,7 +337,19 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     if (D > 1 && nk >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPS_MIN) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS for everyone
-    if (EPI == HI3D_EPI_AFFINE && tid < VSLOT / 16) {   // so are both vector slots (requested before stage 0): fold them
+    if (BIAS_INIT) {                              // so are both vector slots (requested before stage 0)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cl = (wn * 16 * NT + fg * 4 * NT + nt * 4) * 4;
+        f32x4 b = *(const f32x4*)(vec_lds + cl);
+        if (EPI == HI3D_EPI_AFFINE) {
+          const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + cl);
+          b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = b;
+      }
+    } else if (EPI == HI3D_EPI_AFFINE && tid < VSLOT / 16) {   // fold them
       f32x4 b = *(const f32x4*)(vec_lds + tid * 16);    // (here, not inside the loop: there it cost 40 registers)
       const f32x4 g = *(const f32x4*)(vec_lds + VSLOT + tid * 16);
       b[0] += g[0]; b[1] += g[1]; b[2] += g[2]; b[3] += g[3];
@@ -477,7 +493,183 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // already staged free the registers); pass 0 is requested together with pass 1, once the first accumulator block
   // is in LDS (earlier, its registers would spill), and is the only one whose latency is exposed
   u32x4 rw1[2][CH];   // (R1 only: a second pair of sets for R2 spills; R2 -- AlphaBlender tails -- stays a load at the point of use)
+  if (p.abl & 2) return;
   const int osz = p.out_fp32 ? 4 : 2;
+  // ---- wide tiles (256 x 256 / 320, one block per CU: nothing else on the CU hides the epilogue): every WAVE stages
+  // its own 64 x 16*NT tile, 16 rows at a time, through a private LDS slab -- no block barrier after the first one,
+  // the LDS unit keeps a wave's writes and reads in order -- and issues its residual loads / stores row-contiguous,
+  // 16 bytes per lane.  The block-wide form below cost 16 k cycles per tile before any store traffic (ablation:
+  // profiles/r02c_gemm_epilogue_ablation.log), as much as 6 K steps: 8 barriers, each waiting for the slowest wave.
+  constexpr bool WEPI = NT > 5 && WM == 4;
+  if constexpr (WEPI) {
+    constexpr int WOUT = (EPI == HI3D_EPI_GEGLU) ? 8 * NT : 16 * NT;   // output columns of a wave tile
+    constexpr int WROW = WOUT * 4 + 16;                                  // slab row pitch (bytes)
+    constexpr int WSLAB = 16 * WROW;
+    static_assert(NW * WSLAB <= NS * STAGE, "per-wave epilogue slabs do not fit the LDS ring");
+    constexpr int WCPR = WOUT / 8;                                       // 8-column chunks per row
+    constexpr int WCH = (16 * WCPR + 63) / 64;                           // chunks per lane and pass
+    char* const slab = smem + w * WSLAB;
+    const int wcol0 = n0_out + wn * WOUT;                                // first output column of this wave
+    const long wrow0 = (long)m0 + wm * 64;                               // first row of this wave
+    const __amdgpu_buffer_rsrc_t rsOw =
+        __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
+    // chunk i of a pass = lane + 64 i: slab row / column, the same in all four passes -- its LDS, bias, output and
+    // residual offsets are computed once per tile (the store loop was VALU-bound on this index arithmetic: ~80
+    // instructions per chunk, 20 chunks per wave; the accumulators leave ~30 registers for it)
+    int w_row[WCH], w_col[WCH], w_lds[WCH];
+    unsigned w_out[WCH], w_r1[WCH], w_r2[WCH];
+    const int rows_left = p.M - (int)wrow0;                   // rows of this wave's 64 that exist
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = lane + 64 * i;
+      w_row[i] = c / WCPR;
+      w_col[i] = (c - w_row[i] * WCPR) * 8;
+      const bool in = c < 16 * WCPR && wcol0 + w_col[i] < N_out;
+      w_lds[i] = in ? w_row[i] * WROW + w_col[i] * 4 : 0;      // (void chunks read slab bytes 0..31 and store nothing)
+      w_out[i] = in ? (unsigned)((w_row[i] * p.ldo + w_col[i]) * osz) : INV;
+      w_r1[i] = in ? (unsigned)((w_row[i] * p.ldr1 + w_col[i]) * 2) : INV;
+      w_r2[i] = in ? (unsigned)((w_row[i] * p.ldr2 + w_col[i]) * 2) : INV;
+    }
+    const __amdgpu_buffer_rsrc_t rsR1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.R1 ? p.R1 : (const unsigned short*)p.W) + wrow0 * p.ldr1 + wcol0), 0, p.R1 ? 0x7fffffff : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.R2 ? p.R2 : (const unsigned short*)p.W) + wrow0 * p.ldr2 + wcol0), 0, p.R2 ? 0x7fffffff : 0, 0x00020000);
+    auto wc_ok = [&](int i, int mt) { return w_row[i] + mt * 16 < rows_left; };
+    auto wfetch1 = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned (&off)[WCH], int ldr, int mt, int i) -> u32x4 {
+      const int so = mt * 16 * ldr * 2;
+      const bool has8 = wcol0 + w_col[i] + 8 <= N_out;
+      const unsigned vo = wc_ok(i, mt) ? off[i] : INV;
+      if (has8 && p.vec8) return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+      const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);   // 8-byte pieces: narrow or unaligned rows
+      const u32x2 hi2 = __builtin_amdgcn_raw_buffer_load_b64(rs, has8 ? vo + 8 : INV, so, 0);
+      return u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+    };
+    auto wfetch = [&](int mt, u32x4 (&dst)[WCH]) {
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) dst[i] = wfetch1(rsR1, w_r1, p.ldr1, mt, i);
+    };
+    const bool wfast = !p.out_fp32 && p.vec8 && rows_left >= 64 && wcol0 + WOUT <= N_out && (ugrp || !(p.rowvec || p.a1 || p.a2));
+    u32x4 q1[2][WCH];        // (R2 -- AlphaBlender tails -- is loaded at the point of use: a third register set spills)
+    __syncthreads();                               // every wave is done with the operand ring
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      char* trow = slab + fr * WROW;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cw = fg * 4 * NT + nt * 4;       // wave-local column of acc[mt][nt][0]
+        f32x4 v = acc[mt][nt];
+        if (EPI == HI3D_EPI_GEGLU) {
+          if (!BIAS_INIT) {
+            const f32x4 b = *(const f32x4*)(vec_lds + (wn * 16 * NT + cw) * 4);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+          }
+          const hi3d_f2 gl = gelu_erf_f2(hi3d_f2{v[2], v[3]});
+          float2 o; o.x = v[0] * gl[0]; o.y = v[1] * gl[1];
+          *(float2*)(trow + (cw >> 1) * 4) = o;
+        } else {
+          *(f32x4*)(trow + cw * 4) = v;
+        }
+      }
+      if (EPI == HI3D_EPI_AFFINE && p.R1) {        // residual slabs one pass ahead (pass 0 together with pass 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt == 0) wfetch(0, q1[0]);
+        if (mt + 1 < 4) wfetch(mt + 1, q1[(mt + 1) & 1]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // interior wave tiles of the usual call (bf16 out, 16-byte rows, one group per tile, no ragged chunk): no
+      // per-lane predicate and no per-chunk mode branch -- ~25 VALU instructions per chunk instead of ~80
+      if (wfast) {
+        const int so = mt * 16 * p.ldo * osz;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+          const f32x4 lo = *(const f32x4*)(slab + w_lds[i]), hi = *(const f32x4*)(slab + w_lds[i] + 16);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (EPI == HI3D_EPI_AFFINE) {
+            if (!BIAS_INIT) {
+              const char* bp = vec_lds + (wn * WOUT + w_col[i]) * 4;
+              const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 16);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+            }
+            if (p.R1) {
+              const u32x4 r = q1[mt & 1][i];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(r[j] << 16); v[2 * j + 1] += __uint_as_float(r[j] & 0xffff0000u); }
+            }
+            if (p.a1) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= ts1;
+            }
+            if (p.R2) {
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsR2, w_r2[i], mt * 16 * p.ldr2 * 2, 0);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[2 * j] += ts2 * __uint_as_float(r[j] << 16); v[2 * j + 1] += ts2 * __uint_as_float(r[j] & 0xffff0000u); }
+            }
+          }
+          const u32x4 pk = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rsOw, (p.abl & 1) ? INV : w_out[i], so, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) {
+        const int col = w_col[i], row = w_row[i];
+        const bool ok = wc_ok(i, mt) && w_out[i] != INV;
+        const int n = wcol0 + col;
+        const bool has8 = n + 8 <= N_out;
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (w_out[i] != INV) { lo = *(const f32x4*)(slab + w_lds[i]); hi = *(const f32x4*)(slab + w_lds[i] + 16); }
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (EPI == HI3D_EPI_AFFINE) {
+          if (!BIAS_INIT) {
+            const char* bp = vec_lds + (wn * WOUT + col) * 4;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+          }
+          const long m = wrow0 + mt * 16 + row;
+          const int grp = (ok && !ugrp && (p.rowvec || p.a1 || p.a2)) ? (int)(m / p.rpg) : 0;
+          if (p.rowvec && !ugrp && ok) {
+            const float* rv = p.rowvec + (long)grp * p.ldrv + n;
+            const f32x4 r0 = *(const f32x4*)rv;
+            v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
+            if (has8) { const f32x4 r1 = *(const f32x4*)(rv + 4); v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3]; }
+          }
+          if (p.R1) {
+            const u32x4 r = q1[mt & 1][i];
+            v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
+            v[4] += bf16_to_f32(r[2] & 0xffff); v[5] += bf16_to_f32(r[2] >> 16); v[6] += bf16_to_f32(r[3] & 0xffff); v[7] += bf16_to_f32(r[3] >> 16);
+          }
+          if (p.a1) { const float s1 = ugrp ? ts1 : p.a1[grp];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= s1; }
+          if (p.R2) {
+            const float s2 = ugrp ? ts2 : (p.a2 ? p.a2[grp] : 1.0f);
+            const u32x4 r = wfetch1(rsR2, w_r2, p.ldr2, mt, i);
+            v[0] += s2 * bf16_to_f32(r[0] & 0xffff); v[1] += s2 * bf16_to_f32(r[0] >> 16); v[2] += s2 * bf16_to_f32(r[1] & 0xffff); v[3] += s2 * bf16_to_f32(r[1] >> 16);
+            v[4] += s2 * bf16_to_f32(r[2] & 0xffff); v[5] += s2 * bf16_to_f32(r[2] >> 16); v[6] += s2 * bf16_to_f32(r[3] & 0xffff); v[7] += s2 * bf16_to_f32(r[3] >> 16);
+          }
+        }
+        const unsigned vo = (ok && !(p.abl & 1)) ? w_out[i] : INV;
+        const int so = mt * 16 * p.ldo * osz;
+        if (p.out_fp32) {
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsOw, vo, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsOw, has8 ? vo + 16 : INV, so, 0);
+        } else {
+          const u32x4 pk = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+          if (has8 && p.vec8) {
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rsOw, vo, so, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rsOw, vo, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[2], pk[3]}, rsOw, has8 ? vo + 8 : INV, so, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rsO =
       __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
   __syncthreads();                                 // every wave is done with the operand ring
@@ -548,7 +740,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         }
       }
       // stores through the descriptor: out-of-range chunks carry the INV offset and are dropped
-      const unsigned vo = ok ? (unsigned)((chunk_row(i) * p.ldo + col) * osz) : INV;
+      const unsigned vo = (ok && !(p.abl & 1)) ? (unsigned)((chunk_row(i) * p.ldo + col) * osz) : INV;
       const int so = half * 16 * MPP * p.ldo * osz;
       if (p.out_fp32) {
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsO, vo, so, 0);
@@ -684,6 +876,8 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   const int bm = (variant == 2 || variant >= 5) ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
+  p.abl = 0;
+  if (const char* e = getenv("HI3D_GEMM_ABL")) p.abl = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   if (tile == 256) return dispatch<4, 8, 2, true>(p, d->amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);

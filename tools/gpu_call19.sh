@@ -1,0 +1,12 @@
+#!/bin/bash
+O=gpurun_out/r02c; mkdir -p $O
+{
+for abl in 0 1 2; do
+ echo "== variant 7 ABL=$abl"
+ HI3D_GEMM_ABL=$abl HI3D_GEMM_VARIANT=7 python tools/kbench.py one geglu 131072 5120 640
+ HI3D_GEMM_ABL=$abl HI3D_GEMM_VARIANT=7 python tools/kbench.py one plain 131072 5120 640
+ HI3D_GEMM_ABL=$abl HI3D_GEMM_VARIANT=7 python tools/kbench.py one plain 524288 960 320
+ HI3D_GEMM_ABL=$abl HI3D_GEMM_VARIANT=7 python tools/kbench.py one res 131072 640 2560
+done
+} 2>&1 | grep -v amdgpu.ids > $O/gemm_epilogue_ablation.log
+cat $O/gemm_epilogue_ablation.log
