@@ -862,7 +862,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     return d->tile_n == 0 && d->N >= tn && nbn * tn * 100 <= (long)d->N * 107 && ((long)(d->M + 255) / 256) * nbn >= 256;
   };
   if (d->amode == HI3D_A_DENSE) {
-    if (d->epi == HI3D_EPI_GEGLU) variant = (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);
+    if (d->epi == HI3D_EPI_GEGLU) variant = wide_fits(320) ? 7 : (d->K >= 640 && d->N % 320 == 0 && d->M >= 32768) ? 5 : (d->K >= 1280 ? 2 : 3);
     else if (wide_fits(320)) variant = 7;       // (since the residual slabs are requested a store pass ahead: also N = 320 / 640 with short K)
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
   } else if (wide_fits(320)) {

@@ -102,7 +102,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -158,9 +158,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "attn1":
 def bench_ffn():
     """kbench.py ffn : fused GEGLU feed-forward vs GEGLU GEMM + second GEMM at the 320-channel level."""
     C = 320
+    zero = len(sys.argv) > 2 and sys.argv[2] == "zero"     # power probe: no operand toggling
     for M in (524288, 131072):
         x, R1 = rb(M, C), rb(M, C)
         w1, w2 = rb(8 * C, C), rb(C, 4 * C)
+        if zero:
+            x.zero_(); w1.zero_(); w2.zero_(); R1.zero_()
         b1, b2 = torch.randn(8 * C, device=dev), torch.randn(C, device=dev)
         out = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
         gg = torch.empty((M, 4 * C), device=dev, dtype=torch.bfloat16)
@@ -256,3 +259,24 @@ def bench_sweep():
 
 if len(sys.argv) > 1 and sys.argv[1] == "sweep":
     bench_sweep()
+
+
+def bench_conv_one():
+    """kbench.py conv1 F H Cin Cout [res] : one stride-1 conv3x3 shape, few iterations (for rocprofv3 --pmc); prints
+    the algorithmic bytes of a launch (input once + weights + output [+ residual]) next to the time."""
+    Fr, H, Cin, Cout = (int(a) for a in sys.argv[2:6])
+    res = len(sys.argv) > 6 and sys.argv[6] == "res"
+    M, K = Fr * H * H, 9 * Cin
+    A, W = rb(M, Cin), rb(Cout, K)
+    bias = torch.randn(Cout, device=dev)
+    R1 = rb(M, Cout) if res else None
+    out = torch.empty((M, Cout), device=dev, dtype=torch.bfloat16)
+    geo = dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up2x=0)
+    ms = timeit(lambda: ops.gemm(A, W, M=M, N=Cout, K=K, bias=bias, R1=R1, conv3x3=geo, out=out), iters=3, warm=1)
+    alg = 2.0 * (M * Cin + Cout * K + M * Cout * (2 if res else 1))
+    print(f"conv F={Fr} H={H} {Cin}->{Cout}{' +R1' if res else ''}: {ms:.3f} ms {2.0 * M * Cout * K / ms / 1e9:.1f} TFLOP/s  "
+          f"algorithmic {alg / 1e6:.1f} MB/launch (weights {2.0 * Cout * K / 1e6:.1f} MB)")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "conv1":
+    bench_conv_one()

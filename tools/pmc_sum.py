@@ -13,6 +13,8 @@ from collections import defaultdict
 root = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 SIMDS = 256 * 4
+XCDS = 8          # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (149.9 M "cycles" for a 9.6 ms kernel = 8 x 1.95 GHz):
+                  # chip cycles = GRBM_GUI_ACTIVE / 8
 
 
 def short(name):
@@ -37,7 +39,7 @@ for k in kernels[:40]:
     avg = {c: acc[(k, c)] / cnt[(k, c)] for c in counters if (k, c) in cnt}
     util = valu = ""
     if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and avg.get("GRBM_GUI_ACTIVE"):
-        util = f"{100.0 * avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (avg['GRBM_GUI_ACTIVE'] * SIMDS):.1f}"
+        util = f"{100.0 * avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (avg['GRBM_GUI_ACTIVE'] / XCDS * SIMDS):.1f}"
     if "SQ_ACTIVE_INST_VALU" in avg and avg.get("GRBM_GUI_ACTIVE"):      # quad-cycles of VALU issue per SIMD-cycle
-        valu = f"{100.0 * 4.0 * avg['SQ_ACTIVE_INST_VALU'] / (avg['GRBM_GUI_ACTIVE'] * SIMDS):.1f}"
+        valu = f"{100.0 * 4.0 * avg['SQ_ACTIVE_INST_VALU'] / (avg['GRBM_GUI_ACTIVE'] / XCDS * SIMDS):.1f}"
     print(f"\"{k}\",{n}," + ",".join(f"{avg.get(c, 0.0):.0f}" for c in counters) + f",{util},{valu}")

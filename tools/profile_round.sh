@@ -32,6 +32,22 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTI
   python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.csv 2>&1
   rm -rf /tmp/pmc_sq$i
 done
+# conv3x3 traffic per shape: FETCH_SIZE counts Infinity-Cache hits too, so the weights -- re-streamed
+# from the 256 MB cache once per wave of m-tiles when K*N*2 exceeds the 4 MB L2 -- show up in it; the three levels separate
+# the input halo (small weights, 128^2) from the weight stream (29.5 MB of weights, 32^2)
+for shape in "32 128 320 320 res" "32 64 640 640 res" "32 32 1280 1280 res" "32 128 960 320"; do
+  tag=$(echo $shape | tr ' ' '_')
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_cv -o run --output-format csv -- python $R/tools/kbench.py conv1 $shape > $O/pmc_conv_${tag}_$c.log 2>&1
+    echo "== conv1 $shape  $c" >> $O/conv_traffic_per_shape.txt
+    grep "^conv F" $O/pmc_conv_${tag}_$c.log >> $O/conv_traffic_per_shape.txt
+    python $R/tools/pmc_traffic.py /tmp/pmc_cv $c | grep -i "gemm_bf16\|kernel," >> $O/conv_traffic_per_shape.txt
+    rm -rf /tmp/pmc_cv
+  done
+done
+cat $O/conv_traffic_per_shape.txt
+cd $R; python tools/kbench.py sweep h 0 5 7 > $O/gemm_variant_sweep.log 2>&1; cd /tmp
+grep "geglu" $O/gemm_variant_sweep.log
 cat $O/s2_bench.json | cut -c1-700
 cat $O/s1_bench.json | cut -c1-300
 cat $O/vae_bench.json | cut -c1-400
