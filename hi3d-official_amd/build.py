@@ -59,9 +59,9 @@ def _collect_resources(out, table):
 
 
 def _spill_tolerated(mangled):
-    """The 256 x 320 tile (WM=4, NT=10) is only dispatched for the GEGLU epilogue (no scratch there); its affine /
-    conv instantiations exist for HI3D_GEMM_VARIANT=5 experiments and are known to spill."""
-    return "gemm_bf16_kernelILi4ELi10E" in mangled
+    """No instantiation may spill (round 2: the 256 x 320 affine / conv forms, tolerated until then, are dispatched now
+    and fit since the bias fold left the K loop)."""
+    return False
 
 
 def build(force=False, verbose=True):

@@ -36,6 +36,36 @@ __global__ void silu_kernel(const float* __restrict__ x, unsigned short* __restr
     y[i] = f32_to_bf16(silu_f(x[i]));
 }
 
+// Activations of the CLIP vision towers of the conditioner, in place on bf16, 8 elements per thread:
+// kind 0 = exact-erf GELU (nn.GELU: OpenCLIP ViT-H/14), kind 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI ViT-L/14)
+__global__ void act_bf16_kernel(uint4* __restrict__ x, long n8, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    uint4 v = x[i];
+    unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = bf16_to_f32(u[j] & 0xffff), b = bf16_to_f32(u[j] >> 16);
+      if (kind == 0) { a = gelu_erf_f(a); b = gelu_erf_f(b); }
+      else {
+        a = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * a));
+        b = b * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * b));
+      }
+      u[j] = pack_bf16x2(a, b);
+    }
+    x[i] = make_uint4(u[0], u[1], u[2], u[3]);
+  }
+}
+
+// x[r][:] /= ||x[r]||_2 (a zero row stays zero), fp32, one wave per row: tools/aes_score.py `normalized`
+__global__ __launch_bounds__(64) void l2_normalize_rows_kernel(float* __restrict__ x, int C) {
+  float* row = x + (long)blockIdx.x * C;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) ss += row[c] * row[c];
+  ss = wave_sum(ss);
+  const float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 1.0f;
+  for (int c = threadIdx.x; c < C; c += 64) row[c] *= inv;
+}
+
 // one thread per (u, t, pixel): gathers 4 + Cc channel planes (NCHW fp32) into a
 // padded channels-last bf16 row
 __global__ void cfg_prepare_kernel(const float* __restrict__ x, const float* __restrict__ cu,
@@ -281,6 +311,24 @@ extern "C" int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* s
   if (!x || !y) HI3D_FAIL(HI3D_EINVAL, "silu: null pointer");
   if (n <= 0) HI3D_FAIL(HI3D_EINVAL, "silu: non-positive size");
   hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, (long)n);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream) {
+  if (!x) HI3D_FAIL(HI3D_EINVAL, "act: null pointer");
+  if (n <= 0 || (n % 8)) HI3D_FAIL(HI3D_ESHAPE, "act: n must be a positive multiple of 8");
+  if (kind != 0 && kind != 1) HI3D_FAIL(HI3D_EINVAL, "act: kind must be 0 (gelu) or 1 (quick_gelu)");
+  if ((uintptr_t)x & 15) HI3D_FAIL(HI3D_EALIGN, "act: x not 16-byte aligned");
+  hipLaunchKernelGGL(act_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)x, (long)(n / 8), kind);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_l2_normalize_rows(float* x, int32_t R, int32_t C, void* stream) {
+  if (!x) HI3D_FAIL(HI3D_EINVAL, "l2_normalize: null pointer");
+  if (R <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "l2_normalize: non-positive size");
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, x, C);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -370,6 +370,24 @@ def softmax_rows(s, R, N, ldp, scale):
     return p
 
 
+def act_(x, kind):
+    """In-place activation of a contiguous bf16 tensor: kind 'gelu' (exact erf) or 'quick_gelu' (x sigmoid(1.702 x))."""
+    _chk_dev(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise _l.Hi3dError("act_: contiguous bf16 tensor required")
+    _l.check(_lib.hi3d_act_bf16(_p(x), x.numel(), {"gelu": 0, "quick_gelu": 1}[kind], _stream()), "hi3d_act_bf16")
+    return x
+
+
+def l2_normalize_rows_(x):
+    """x fp32 [R, C] contiguous: every row divided by its L2 norm, in place."""
+    _chk_dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 2:
+        raise _l.Hi3dError("l2_normalize_rows_: contiguous fp32 [R, C] required")
+    _l.check(_lib.hi3d_l2_normalize_rows(_p(x), x.shape[0], x.shape[1], _stream()), "hi3d_l2_normalize_rows")
+    return x
+
+
 def vae_posterior(mom, wq, bq, noise, N, Cz, H, W):
     """mom fp32 [N*H*W, ldm] -> z fp32 [N, Cz, H, W] (sample if noise is given, else the mode)."""
     z = torch.empty((N, Cz, H, W), device=mom.device, dtype=torch.float32)

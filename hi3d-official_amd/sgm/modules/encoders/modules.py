@@ -1,10 +1,11 @@
 """Conditioner container (reference: sgm/modules/encoders/modules.py:71-184).
 
-The Hi3D conditioner runs ONCE per clip (OpenCLIP ViT-H image tower, MiDaS depth, VAE
+The Hi3D conditioner runs ONCE per clip (OpenCLIP ViT-H image tower, aesthetic score, MiDaS depth, VAE
 encoder of the conditioning frame ...) and is outside the denoising hot path this
-framework covers (SURVEY.md section 8, rank-3 "next").  Built here: the scalar embedders and
-the conditioning-frame VAE embedder (it reuses the gfx950 VAE encoder); the CLIP and MiDaS
-towers are not.  What the hot path consumes is its
+framework covers (SURVEY.md section 8, rank-3 "next").  Built here: the scalar embedders, the
+conditioning-frame VAE embedder (it reuses the gfx950 VAE encoder) and the CLIP vision towers
+(`FrozenOpenCLIPImageEmbedder` here, `AesEmbedder` in vtdm/encoders.py, both on hi3d_hip.runtime_vit); the MiDaS
+DPT-hybrid depth tower is not.  What the hot path consumes is its
 OUTPUT: `c` / `uc` dicts with keys crossattn [B,1,1024], vector [B,adm], concat
 [T,Cc,h,w].  This container keeps the reference's combining rules for embedders that
 are available and reports the ones that are not, by name, when it is asked to run them.
@@ -71,6 +72,139 @@ class VideoPredictionEmbedderWithEncoder(AbstractEmbModel):
         return z.expand(b, self.n_copies, self.n_cond_frames * c, h, w).reshape(b * self.n_copies, self.n_cond_frames * c, h, w)
 
 
+# CLIP vision-tower geometries (open_clip model_configs/ViT-H-14.json; OpenAI clip ViT-L/14): width, layers, heads,
+# patch, image size, output dim, MLP activation
+CLIP_VISUAL_ARCHS = {
+    "ViT-H-14": dict(width=1280, layers=32, heads=16, patch=14, image=224, out_dim=1024, act="gelu"),
+    "ViT-L-14": dict(width=1024, layers=24, heads=16, patch=14, image=224, out_dim=768, act="quick_gelu"),
+    # reduced towers for tests (same code path: head dim 80 / 64, same output widths)
+    "ViT-tiny-H": dict(width=320, layers=2, heads=4, patch=14, image=224, out_dim=1024, act="gelu"),
+    "ViT-tiny-L": dict(width=128, layers=2, heads=2, patch=14, image=224, out_dim=768, act="quick_gelu"),
+}
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_visual_shapes(width, layers, patch, image, out_dim, **_):
+    """{open_clip / OpenAI-clip visual state_dict key: shape}"""
+    g = image // patch
+    s = {"conv1.weight": (width, 3, patch, patch), "class_embedding": (width,), "positional_embedding": (1 + g * g, width),
+         "proj": (width, out_dim)}
+    for n in ("ln_pre", "ln_post"):
+        s[n + ".weight"], s[n + ".bias"] = (width,), (width,)
+    for i in range(layers):
+        p = f"transformer.resblocks.{i}."
+        for n in ("ln_1", "ln_2"):
+            s[p + n + ".weight"], s[p + n + ".bias"] = (width,), (width,)
+        s[p + "attn.in_proj_weight"], s[p + "attn.in_proj_bias"] = (3 * width, width), (3 * width,)
+        s[p + "attn.out_proj.weight"], s[p + "attn.out_proj.bias"] = (width, width), (width,)
+        s[p + "mlp.c_fc.weight"], s[p + "mlp.c_fc.bias"] = (4 * width, width), (4 * width,)
+        s[p + "mlp.c_proj.weight"], s[p + "mlp.c_proj.bias"] = (width, 4 * width), (width,)
+    return s
+
+
+class _ClipVisualTower(nn.Module):
+    """Parameters of a CLIP vision tower under `<name>.visual.*` (the reference keeps the whole open_clip / clip
+    model minus its text transformer; only `visual.*` carries weights the image path uses) + the packed gfx950
+    runtime, rebuilt when any parameter changes."""
+
+    def __init__(self, arch_cfg):
+        super().__init__()
+        from ...util import ParamTree
+        self.cfg = dict(arch_cfg)
+        self.visual = ParamTree(clip_visual_shapes(**self.cfg))
+        self._rt = None
+
+    def runtime(self, device):
+        from hi3d_hip.runtime_vit import ViTRuntime
+        from ...util import params_key
+        key = params_key(self, device)
+        if self._rt is None or self._rt[0] != key:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._rt = (key, ViTRuntime(sd, "visual.", self.cfg["heads"], self.cfg["act"], device))
+        return self._rt[1]
+
+
+class FrozenOpenCLIPImageEmbedder(AbstractEmbModel):
+    """OpenCLIP vision-transformer image encoder (reference :570-728) on the gfx950 ViT runtime.
+
+    The reference downloads / loads `version` through open_clip.create_model_and_transforms; here the tower's
+    parameters are a ParamTree under the same names (`model.visual.*`): load them with load_state_dict from an
+    open_clip checkpoint (`init_from_open_clip_ckpt`), nothing is fetched.  Inference surface: `output_tokens`
+    and multi-crop inputs are refused (unused by the Hi3D configs)."""
+
+    def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True,
+                 antialias=True, ucg_rate=0.0, unsqueeze_dim=False, repeat_to_max_len=False, num_image_crops=0,
+                 output_tokens=False, init_device=None):
+        super().__init__()
+        if arch not in CLIP_VISUAL_ARCHS:
+            raise NotImplementedError(f"FrozenOpenCLIPImageEmbedder: arch {arch} (known: {sorted(CLIP_VISUAL_ARCHS)})")
+        if output_tokens or num_image_crops:
+            raise NotImplementedError("FrozenOpenCLIPImageEmbedder: output_tokens / num_image_crops are not wired")
+        self.model = _ClipVisualTower(CLIP_VISUAL_ARCHS[arch])
+        self.version, self.device, self.max_length = version, device, max_length
+        self.antialias, self.ucg_rate, self.unsqueeze_dim = antialias, ucg_rate, unsqueeze_dim
+        self.repeat_to_max_len, self.max_crops, self.output_tokens = repeat_to_max_len, 0, False
+        self.register_buffer("mean", torch.tensor(CLIP_MEAN), persistent=False)
+        self.register_buffer("std", torch.tensor(CLIP_STD), persistent=False)
+        if freeze:
+            self.freeze()
+
+    def freeze(self):
+        self.model = self.model.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def init_from_open_clip_ckpt(self, path):
+        """open_clip_pytorch_model.bin / a clip state_dict: keeps `visual.*`, drops the text tower."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        vis = {k: v.float() for k, v in sd.items() if k.startswith("visual.")}
+        missing, unexpected = self.model.load_state_dict(vis, strict=False)
+        if missing:
+            raise KeyError(f"open_clip checkpoint lacks {len(missing)} visual keys, e.g. {missing[:3]}")
+
+    def preprocess(self, x):
+        """[-1,1] image -> 224 x 224 (bicubic, antialias, align_corners: kornia.geometry.resize in the reference, :618-630;
+        torch's interpolate here -- kornia is a torch wrapper and absent) -> [0,1] -> CLIP mean / std."""
+        size = self.model.cfg["image"]
+        if tuple(x.shape[-2:]) != (size, size):
+            x = torch.nn.functional.interpolate(x.float(), (size, size), mode="bicubic", align_corners=True, antialias=self.antialias)
+        x = (x + 1.0) / 2.0
+        return (x - self.mean.to(x.device).view(1, 3, 1, 1)) / self.std.to(x.device).view(1, 3, 1, 1)
+
+    def forward(self, image, no_dropout=False):
+        dev = image.device if image.is_cuda else torch.device(self.device)
+        z = self.model.runtime(dev).forward(self.preprocess(image.to(dev))).to(image.dtype)
+        if self.ucg_rate > 0.0 and not no_dropout:
+            z = torch.bernoulli((1.0 - self.ucg_rate) * torch.ones(z.shape[0], device=z.device))[:, None] * z
+        if self.unsqueeze_dim:
+            z = z[:, None, :]
+        if self.repeat_to_max_len:
+            z_ = z[:, None, :] if z.dim() == 2 else z
+            return z_.expand(z_.shape[0], self.max_length, z_.shape[-1]), z
+        return z
+
+    def encode(self, image):
+        return self(image)
+
+
+class FrozenOpenCLIPImagePredictionEmbedder(AbstractEmbModel):
+    """`crossattn` conditioning: CLIP embedding of the conditioning frame(s), "(b t) d -> b t d", repeated for the
+    n_copies views (reference :1028-1046)."""
+
+    def __init__(self, open_clip_embedding_config=None, n_cond_frames=1, n_copies=1):
+        super().__init__()
+        self.n_cond_frames, self.n_copies = n_cond_frames, n_copies
+        cfg = open_clip_embedding_config or {"target": "sgm.modules.encoders.modules.FrozenOpenCLIPImageEmbedder"}
+        self.open_clip = instantiate_from_config(cfg)
+
+    def forward(self, vid):
+        z = self.open_clip(vid)
+        z = z.reshape(-1, self.n_cond_frames, z.shape[-1])
+        return z.repeat_interleave(self.n_copies, dim=0)
+
+
 class _Unavailable(AbstractEmbModel):
     def __init__(self, target, error):
         super().__init__()
@@ -93,7 +227,7 @@ class GeneralConditioner(nn.Module):
         for cfg in emb_models or []:
             try:
                 emb = instantiate_from_config(cfg)
-            except (ImportError, AttributeError, ModuleNotFoundError) as e:
+            except (ImportError, AttributeError, ModuleNotFoundError, NotImplementedError) as e:
                 emb = _Unavailable(cfg["target"], f"{type(e).__name__}: {e}")
             emb.is_trainable = cfg.get("is_trainable", False)
             emb.ucg_rate = cfg.get("ucg_rate", 0.0)

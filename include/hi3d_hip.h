@@ -214,6 +214,15 @@ int hi3d_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
  * openaimodel.py:284-286), n elements                                        */
 int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
+/* In-place activation on n bf16 elements (n % 8 == 0) -- the MLP of the conditioner's CLIP vision towers:
+ * kind 0: exact-erf GELU (open_clip ViT-H/14 `nn.GELU`, sgm/modules/encoders/modules.py:592-596 builds the tower),
+ * kind 1: QuickGELU x * sigmoid(1.702 x) (OpenAI CLIP ViT-L/14 of vtdm/encoders.py:59).                   */
+int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream);
+
+/* x[r] /= ||x[r]||_2 in place, fp32 [R][C]; zero rows stay zero (tools/aes_score.py:56-61 `normalized`,
+ * applied to the CLIP image features before the aesthetic MLP, vtdm/encoders.py:88-89)                   */
+int hi3d_l2_normalize_rows(float* x, int32_t R, int32_t C, void* stream);
+
 /* Build the UNet input for one CFG-doubled step (guiders.py:88-99 prepare_inputs,
  * denoiser.py:36-37 `input * c_in`, wrappers.py:26 cat with c["concat"]) directly
  * in padded channels-last bf16:

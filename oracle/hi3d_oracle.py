@@ -393,3 +393,82 @@ def video_decode(sd, dd, z, T, prefix="first_stage_model."):
     h5 = h.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)                                   # ... then time_mix_conv
     h5 = F.conv3d(h5, sd[D + "conv_out.time_mix_conv.weight"], sd[D + "conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
     return h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+
+
+# --------------------------------------------------------------------------------------
+# conditioner: CLIP vision towers (once per clip)
+# --------------------------------------------------------------------------------------
+# PARITY PIN: the towers live in third-party packages that are absent from /root/reference and from this
+# container -- open_clip (environments.yaml:151 `open-clip-torch==2.24.0`, ViT-H-14 / laion2b_s32b_b79k, built at
+# sgm/modules/encoders/modules.py:592-596 and called at :700-704) and OpenAI `clip` (environments.yaml:53
+# `clip==1.0`, ViT-L/14, vtdm/encoders.py:59,86).  This restates their published VisionTransformer forward
+# (open_clip/transformer.py `VisionTransformer.forward` with pool_type 'tok', no patch dropout; clip/model.py
+# `VisionTransformer.forward`), keyed by THEIR state_dict names, and is pinned against an independent
+# implementation of the same architecture that IS installed here: HuggingFace `transformers.CLIPVisionModelWithProjection`
+# (its conversion script maps exactly these names) -- oracle/gen_golden_clip.py -> tests/golden/clip_*.pt.
+# Pinned against the reference's own packages it is not: "parity unpinned" for open_clip / clip proper.
+def clip_visual(sd, img, heads, act="gelu", prefix="visual."):
+    """img fp32 [B,3,H,W] (already CLIP-normalised) -> pooled, projected embedding [B, out_dim].
+
+    sd keys (open_clip / OpenAI clip): conv1.weight [W,3,p,p]; class_embedding [W]; positional_embedding [1+g*g, W];
+    ln_pre / ln_post; transformer.resblocks.{i}.{ln_1, attn.in_proj_weight [3W,W], attn.in_proj_bias,
+    attn.out_proj, ln_2, mlp.c_fc, mlp.c_proj}; proj [W, out]."""
+    g = lambda k: sd[prefix + k]
+    w = g("conv1.weight")
+    x = F.conv2d(img, w, None, stride=w.shape[-1])                       # [B, W, gh, gw]
+    B, Wd = x.shape[0], x.shape[1]
+    x = x.reshape(B, Wd, -1).permute(0, 2, 1)                            # [B, g*g, W]
+    x = torch.cat([g("class_embedding").reshape(1, 1, Wd).expand(B, 1, Wd), x], dim=1) + g("positional_embedding")[None]
+    x = F.layer_norm(x, (Wd,), g("ln_pre.weight"), g("ln_pre.bias"), 1e-5)
+    i = 0
+    while (prefix + f"transformer.resblocks.{i}.ln_1.weight") in sd:
+        p = f"transformer.resblocks.{i}."
+        h = F.layer_norm(x, (Wd,), g(p + "ln_1.weight"), g(p + "ln_1.bias"), 1e-5)
+        q, k, v = F.linear(h, g(p + "attn.in_proj_weight"), g(p + "attn.in_proj_bias")).chunk(3, dim=-1)
+        S, d = q.shape[1], Wd // heads
+        q, k, v = [t.reshape(B, S, heads, d).transpose(1, 2) for t in (q, k, v)]
+        a = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1) @ v
+        x = x + F.linear(a.transpose(1, 2).reshape(B, S, Wd), g(p + "attn.out_proj.weight"), g(p + "attn.out_proj.bias"))
+        h = F.layer_norm(x, (Wd,), g(p + "ln_2.weight"), g(p + "ln_2.bias"), 1e-5)
+        h = F.linear(h, g(p + "mlp.c_fc.weight"), g(p + "mlp.c_fc.bias"))
+        h = F.gelu(h) if act == "gelu" else h * torch.sigmoid(1.702 * h)  # nn.GELU (ViT-H-14) / QuickGELU (OpenAI ViT-L/14)
+        x = x + F.linear(h, g(p + "mlp.c_proj.weight"), g(p + "mlp.c_proj.bias"))
+        i += 1
+    pooled = F.layer_norm(x[:, 0], (Wd,), g("ln_post.weight"), g("ln_post.bias"), 1e-5)
+    return pooled @ g("proj")
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def openclip_image_embedder(sd, img, heads, n_cond_frames=1, n_copies=1, prefix="open_clip.model.visual.", size=224):
+    """FrozenOpenCLIPImagePredictionEmbedder (sgm/modules/encoders/modules.py:1028-1046) around
+    FrozenOpenCLIPImageEmbedder.forward (:641-692, ucg_rate 0 path): resize to 224 (bicubic, antialias), [-1,1] -> [0,1],
+    CLIP mean / std, vision tower, then "(b t) d -> b t d" and the n_copies repeat.  The reference resizes with
+    kornia.geometry.resize(align_corners=True, antialias=True); kornia is absent here, torch's bicubic + antialias is
+    used in oracle and product alike (an input already 224 x 224 is untouched by either)."""
+    if img.shape[-2:] != (size, size):
+        img = F.interpolate(img, (size, size), mode="bicubic", align_corners=True, antialias=True)
+    x = (img + 1.0) / 2.0
+    x = (x - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    z = clip_visual(sd, x, heads, "gelu", prefix)
+    z = z.reshape(-1, n_cond_frames, z.shape[-1])
+    return z.repeat_interleave(n_copies, dim=0)
+
+
+def aes_embedder(sd, video, heads=16, clip_prefix="aesthetic_model.visual.", mlp_prefix="aesthetic_mlp.layers."):
+    """AesEmbedder.forward (vtdm/encoders.py:73-91): middle frame, bilinear resize to 224 x 384, centre crop 224,
+    CLIP normalisation, OpenAI CLIP ViT-L/14 image features, L2 normalisation (tools/aes_score.py:56-61), the
+    5-layer aesthetic MLP (tools/aes_score.py:21-30, dropouts inert in eval), then [score, timestep_embedding(100 score, 255)]."""
+    B, C, T, H, W = video.shape
+    y = video[:, :, T // 2]
+    y = F.interpolate(y, [224, 384], mode="bilinear")[:, :, :, 80:304]
+    y = (y + 1) * 0.5
+    y = (y - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    f = clip_visual(sd, y, heads, "quick_gelu", clip_prefix)
+    n = f.norm(dim=-1, keepdim=True)
+    f = f / torch.where(n == 0, torch.ones_like(n), n)
+    for i in (0, 2, 4, 6, 7):
+        f = F.linear(f, sd[mlp_prefix + f"{i}.weight"], sd[mlp_prefix + f"{i}.bias"])
+    return torch.cat([f, sinusoid(f[:, 0] * 100, 255)], dim=1)

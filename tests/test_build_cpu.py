@@ -18,10 +18,12 @@ def test_no_hot_kernel_spills_to_scratch():
     assert len(res) > 40
     gemm = {k: v for k, v in res.items() if "gemm_bf16_kernel" in k}
     assert gemm and any("ffn_geglu" in k for k in res) and any("attn_d64" in k for k in res)
-    tolerated = lambda k: "gemm_bf16_kernelILi4ELi10E" in k          # 256x320 tile, affine/conv forms: experiments only
-    spilled = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) and not tolerated(k)}
+    spilled = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0)}
     assert not spilled, spilled
     # the instantiations the stage-2 step actually dispatches keep two blocks per CU (occupancy 2 with 256 threads)
     for k, v in gemm.items():
         if "ILi2ELi5ELi2E" in k:
             assert v["occupancy"] >= 2 and v["vgprs"] <= 256, (k, v)
+    # the ping-pong wide tile the stage-2 convs / QKV / GEGLU run on: 8 waves, two per SIMD
+    wide = [v for k, v in gemm.items() if "ILi4ELi10ELi2E" in k and "Lb1E" in k]
+    assert wide and all(v["vgprs"] <= 256 and v["occupancy"] >= 2 for v in wide)

@@ -222,7 +222,8 @@ def test_create_model_from_yaml_builds_engine():
     if not os.path.exists(cfg):
         pytest.skip("configs not written yet")
     import yaml
-    y = yaml.safe_load(open(cfg))
+    from conftest import shrink_conditioner
+    y = shrink_conditioner(yaml.safe_load(open(cfg)))
     # shrink widths so the CPU test stays cheap; structure/keys are what is checked
     y["model"]["params"]["network_config"]["params"]["model_channels"] = 64
     y["model"]["params"]["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
@@ -236,11 +237,24 @@ def test_create_model_from_yaml_builds_engine():
     assert m.num_samples == 16 and m.sampler.num_steps == 25 and m.sampler.guider.max_scale == 2.5
     assert abs(m.scale_factor - 0.18215) < 1e-9 and m.en_and_decode_n_samples_a_time == 16
     # the conditioning-frame embedder is built on this framework's VAE encoder and keeps the reference's key names
-    from sgm.modules.encoders.modules import ConcatTimestepEmbedderND, VideoPredictionEmbedderWithEncoder, _Unavailable
+    from sgm.modules.encoders.modules import (ConcatTimestepEmbedderND, FrozenOpenCLIPImagePredictionEmbedder,
+                                              VideoPredictionEmbedderWithEncoder)
+    from vtdm.encoders import AesEmbedder
     emb = {e.input_key: e for e in m.conditioner.embedders}
     assert isinstance(emb["cond_frames"], VideoPredictionEmbedderWithEncoder) and emb["cond_frames"].n_copies == 16
     assert isinstance(emb["cond_aug"], ConcatTimestepEmbedderND)
-    assert isinstance(emb["cond_frames_without_noise"], _Unavailable)          # CLIP tower: reported, not built
+    # the CLIP towers keep the reference's parameter names (open_clip / clip `visual.*` under the module tree of
+    # sgm/modules/encoders/modules.py:592-596,1040 and vtdm/encoders.py:59-62)
+    assert isinstance(emb["cond_frames_without_noise"], FrozenOpenCLIPImagePredictionEmbedder)
+    assert isinstance(emb["video"], AesEmbedder)
+    ic = list(m.conditioner.embedders).index(emb["cond_frames_without_noise"])
+    ia = list(m.conditioner.embedders).index(emb["video"])
+    for k in (f"conditioner.embedders.{ic}.open_clip.model.visual.conv1.weight",
+              f"conditioner.embedders.{ic}.open_clip.model.visual.transformer.resblocks.0.attn.in_proj_weight",
+              f"conditioner.embedders.{ic}.open_clip.model.visual.proj",
+              f"conditioner.embedders.{ia}.aesthetic_model.visual.ln_post.weight",
+              f"conditioner.embedders.{ia}.aesthetic_mlp.layers.7.weight"):
+        assert k in keys, k
     i = list(m.conditioner.embedders).index(emb["cond_frames"])
     assert f"conditioner.embedders.{i}.encoder.encoder.conv_in.weight" in keys
     assert f"conditioner.embedders.{i}.encoder.quant_conv.weight" in keys
@@ -289,7 +303,8 @@ def test_init_from_ckpt_three_formats(tmp_path, fmt):
     DeepSpeed .pt {'module': {'module.<key>': ...}} (how first_stage.pt / second_stage.pt ship), safetensors."""
     import yaml
     from vtdm.model import create_model
-    y = yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml")))
+    from conftest import shrink_conditioner
+    y = shrink_conditioner(yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml"))))
     y["model"]["params"]["network_config"]["params"]["model_channels"] = 64
     y["model"]["params"]["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
     cfgp = tmp_path / "cfg.yaml"

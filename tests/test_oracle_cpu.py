@@ -116,3 +116,19 @@ def test_video_decoder_oracle_matches_reference(name):
     with torch.no_grad():
         out = O.video_decode(weights(fx), fx["ddconfig"], fx["z"], fx["T"], prefix=fx["key_prefix"])
     assert rel(out, fx["output"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["clip_vith_like", "clip_vitl_like"])
+def test_clip_visual_oracle_matches_independent_implementation(name):
+    """The CLIP vision tower restatement (original open_clip / OpenAI key names) vs HuggingFace's
+    CLIPVisionModelWithProjection on the same weights (oracle/gen_golden_clip.py): head_dim 80 + GELU as ViT-H/14,
+    head_dim 64 + QuickGELU as ViT-L/14.  open_clip / clip themselves are not installable here: unpinned against them."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle"))
+    from gen_golden_clip import clip_shapes
+    fx = load(name)
+    c = fx["cfg"]
+    sd = synth.synth_state_dict(clip_shapes(c["width"], c["layers"], c["patch"], c["grid"], c["out_dim"]), fx["seed"])
+    out = O.clip_visual(sd, fx["img"], c["heads"], c["act"])
+    assert out.shape == fx["out"].shape
+    assert rel(out, fx["out"]) < TOL

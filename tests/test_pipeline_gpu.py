@@ -18,7 +18,8 @@ def test_stage1_clip_create_model_sample_decode(dev):
     from vtdm.model import create_model
     from vtdm.util import tensor2vid
 
-    y = yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml")))
+    from conftest import shrink_conditioner
+    y = shrink_conditioner(yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml"))))
     P = y["model"]["params"]
     T, steps, hw = 4, 4, 8
     P["num_samples"] = T
