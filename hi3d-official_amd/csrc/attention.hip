@@ -359,18 +359,30 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * PB, h = blockIdx.y, b = blockIdx.z;
 
-  // ---- stage K rows and transposed V: 8 chunks of 16 B per (pixel, frame)
-  for (int c = tid; c < PB * TP * 8; c += 256) {
+  // ---- stage K rows and transposed V: 8 chunks of 16 B per (pixel, frame).  PB * TP * 8 / 256 = 8 chunks per
+  // thread: all 16 loads are issued before the first LDS write (the rolled loop had two loads in flight per thread
+  // and ran the kernel at 3.0 TB/s)
+  constexpr int NCH = PB * TP * 8 / 256;
+  uint4 kq[NCH], vq[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256;
     const int ch = c & 7, row = c >> 3;
     const int t = row % TP, px = row / TP;
-    uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+    kq[i] = make_uint4(0, 0, 0, 0); vq[i] = make_uint4(0, 0, 0, 0);
     if (t < T && s0 + px < S) {
       const long off = (((long)b * T + t) * S + s0 + px) * ld + h * 64 + ch * 8;
-      kq = *(const uint4*)(k + off);
-      vq = *(const uint4*)(v + off);
+      kq[i] = *(const uint4*)(k + off);
+      vq[i] = *(const uint4*)(v + off);
     }
-    *(uint4*)(sK + px * KPIX + t * 128 + ch * 16) = kq;
-    const unsigned int u[4] = {vq.x, vq.y, vq.z, vq.w};
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256;
+    const int ch = c & 7, row = c >> 3;
+    const int t = row % TP, px = row / TP;
+    *(uint4*)(sK + px * KPIX + t * 128 + ch * 16) = kq[i];
+    const unsigned int u[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *(unsigned short*)(sV + px * VPIX + (ch * 8 + 2 * j) * VROW + t * 2) = (unsigned short)(u[j] & 0xffff);
