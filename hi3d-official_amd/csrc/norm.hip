@@ -11,6 +11,7 @@
 //   pass 3  gn_apply    : y = silu(x * a_c + b_c), a_c = rstd*gamma_c, b_c = beta_c - mean*a_c
 // Fixed summation order => bitwise reproducible run to run.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -263,6 +264,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
 }
 
+// ---- LayerNorm for C = 40 * LPR (320 / 640 / 1280: every transformer width of the UNet): LPR lanes per row, five
+// 16-byte vectors per lane, 64 / LPR rows per wave.  The one-wave-per-row kernel above leaves 24 of 64 lanes idle at
+// C = 320 (40 vectors) and runs at 3.3 TB/s there against 4.6 at C = 1280; here every lane is busy at every width and a
+// load instruction covers whole 128-byte lines (LPR consecutive vectors of each of its rows).
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(
+    const uint4* __restrict__ x, uint4* __restrict__ y, uint4* __restrict__ sum_out,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ addvec, int rpg, int R, float eps) {
+  constexpr int NV = 5, RPW = 64 / LPR, vec = NV * LPR, C = vec * 8;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  if (row >= R) return;                        // (uniform over the LPR lanes of a row: the shuffles below stay inside them)
+  const uint4* xr = x + row * vec;
+  const float* av = addvec ? addvec + (row / rpg) * (long)C : nullptr;
+  float f[NV][8];
+  uint4 q[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) q[i] = xr[sub + i * LPR];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = sub + i * LPR;
+    const unsigned int u[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[i][2 * j] = bf16_to_f32(u[j] & 0xffff);
+      f[i][2 * j + 1] = bf16_to_f32(u[j] >> 16);
+    }
+    if (av) {
+      const f32x4 a0 = *(const f32x4*)(av + v * 8), a1 = *(const f32x4*)(av + v * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[i][j] += a0[j]; f[i][4 + j] += a1[j]; }
+      if (sum_out) {
+        sum_out[row * vec + v] = make_uint4(pack_bf16x2(f[i][0], f[i][1]), pack_bf16x2(f[i][2], f[i][3]),
+                                            pack_bf16x2(f[i][4], f[i][5]), pack_bf16x2(f[i][6], f[i][7]));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[i][j];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; ss += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = rsqrtf(ss / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = sub + i * LPR;
+    const f32x4 g0 = *(const f32x4*)(gamma + v * 8), g1 = *(const f32x4*)(gamma + v * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + v * 8), b1 = *(const f32x4*)(beta + v * 8 + 4);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+      o[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+    }
+    y[row * vec + v] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                  pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+}
+
 }  // namespace
 
 extern "C" int32_t hi3d_gn_partial_blocks(int32_t P, int32_t C) {
@@ -353,8 +422,19 @@ extern "C" int hi3d_layernorm(const void* x, void* y, void* sum_out, const float
   if (sum_out && !addvec) HI3D_FAIL(HI3D_EINVAL, "layernorm: sum_out without addvec");
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)sum_out) & 15) HI3D_FAIL(HI3D_EALIGN, "layernorm: not 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int grid = (R + 3) / 4, vec = C / 8;
   const int rpg = rows_per_group < 1 ? 1 : rows_per_group;
+  // widths 320 / 640 / 1280: packed rows, every lane busy (HI3D_LN_PACKED=0 falls back to one wave per row)
+  static const bool packed_on = [] { const char* e = getenv("HI3D_LN_PACKED"); return !e || atoi(e) != 0; }();
+  if (packed_on && (C == 320 || C == 640 || C == 1280)) {
+    const int lpr = C / 40, rows_per_block = 4 * (64 / lpr);
+    const int g = (R + rows_per_block - 1) / rows_per_block;
+#define LNP_LAUNCH(LPR) hipLaunchKernelGGL(layernorm_packed_kernel<LPR>, dim3(g), dim3(256), 0, s, (const uint4*)x, (uint4*)y, (uint4*)sum_out, gamma, beta, addvec, rpg, R, eps)
+    if (lpr == 8) LNP_LAUNCH(8); else if (lpr == 16) LNP_LAUNCH(16); else LNP_LAUNCH(32);
+#undef LNP_LAUNCH
+    HI3D_LAUNCH_CHECK();
+    return HI3D_OK;
+  }
+  const int grid = (R + 3) / 4, vec = C / 8;
 #define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(grid), dim3(256), 0, s, (const uint4*)x, (uint4*)y, (uint4*)sum_out, gamma, beta, addvec, rpg, R, C, eps)
   if (vec <= 64) LN_LAUNCH(1);
   else if (vec <= 128) LN_LAUNCH(2);
