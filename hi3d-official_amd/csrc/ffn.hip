@@ -217,31 +217,70 @@ __global__ __launch_bounds__(FNW * 64, 2) void ffn_geglu_c320_kernel(const FfnPa
     }
   }
 
-  // ---- epilogue: lane (fg, fr) owns row m0 + wm*64 + mt*16 + fr, columns wn*80 + fg*20 + nt*4 .. +3
-  const int nb = wn * 80 + fg * 20;
+  // ---- epilogue.  Lane (fg, fr) owns row m0 + wm*64 + mt*16 + fr, columns wn*80 + fg*20 + nt*4 .. +3: stored from that
+  // layout every load / store instruction is 64 scattered 8-byte requests (~20 k cycles per block, a tenth of its
+  // time).  As in the wide GEMM tiles every wave stages its 64 x 80 tile, 16 rows at a time, through a private fp32
+  // slab in the (now free) LDS and issues residual loads and stores row-contiguous, 16 bytes per lane; residual
+  // slabs are requested one pass ahead.
+  constexpr int EW = 80, EROW = EW * 4 + 16, ESLAB = 16 * EROW, ECPR = EW / 8, ECH = (16 * ECPR + 63) / 64;
+  static_assert(FNW * ESLAB <= FFN_LDS, "epilogue slabs");
+  __syncthreads();                               // every wave is done with the weight / hg slabs
+  char* const slab = smem + w * ESLAB;
+  const int ecol0 = wn * EW;
+  const long erow0 = (long)m0 + wm * 64;
+  const int rows_left = p.M - (int)erow0;
+  int e_row[ECH], e_col[ECH], e_lds[ECH];
+#pragma unroll
+  for (int i = 0; i < ECH; ++i) {
+    const int c = lane + 64 * i;
+    e_row[i] = c / ECPR;
+    e_col[i] = (c - e_row[i] * ECPR) * 8;
+    e_lds[i] = c < 16 * ECPR ? e_row[i] * EROW + e_col[i] * 4 : -1;
+  }
+  auto e_ok = [&](int i, int mt) { return e_lds[i] >= 0 && e_row[i] + mt * 16 < rows_left; };
+  auto fetch = [&](const unsigned short* R, int ldr, int mt, int i) -> u32x4 {
+    if (!R || !e_ok(i, mt)) return u32x4{0u, 0u, 0u, 0u};
+    const unsigned short* rp = R + (erow0 + mt * 16 + e_row[i]) * ldr + ecol0 + e_col[i];
+    if ((ldr & 7) == 0 && (((uintptr_t)R) & 15) == 0) return *(const u32x4*)rp;
+    const u32x2 lo = *(const u32x2*)rp, hi = *(const u32x2*)(rp + 4);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  const bool o16 = (p.ldo & 7) == 0 && (((uintptr_t)p.out) & 15) == 0;
+  u32x4 q1[2][ECH], q2[2][ECH];
+#pragma unroll
+  for (int i = 0; i < ECH; ++i) { q1[0][i] = fetch(p.R1, p.ldr1, 0, i); q2[0][i] = fetch(p.R2, p.ldr2, 0, i); }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fr;
-    if (m >= p.M) continue;
-    const int grp = (p.a1 || p.a2) ? m / p.rpg : 0;
-    const float s1 = p.a1 ? p.a1[grp] : 1.0f;
-    const float s2 = p.a2 ? p.a2[grp] : 1.0f;
-    uint2 r1[5], r2[5];
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      r1[nt] = p.R1 ? *(const uint2*)(p.R1 + (long)m * p.ldr1 + nb + nt * 4) : make_uint2(0, 0);
-      r2[nt] = p.R2 ? *(const uint2*)(p.R2 + (long)m * p.ldr2 + nb + nt * 4) : make_uint2(0, 0);
-    }
+    for (int nt = 0; nt < 5; ++nt) *(f32x4*)(slab + fr * EROW + (fg * 20 + nt * 4) * 4) = acc2[mt][nt];
+    if (mt + 1 < 4) {
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      const f32x4 b = *(const f32x4*)(p.b2 + nb + nt * 4);
-      float v[4];
-      v[0] = (acc2[mt][nt][0] + b[0] + bf16_to_f32(r1[nt].x & 0xffff)) * s1 + s2 * bf16_to_f32(r2[nt].x & 0xffff);
-      v[1] = (acc2[mt][nt][1] + b[1] + bf16_to_f32(r1[nt].x >> 16)) * s1 + s2 * bf16_to_f32(r2[nt].x >> 16);
-      v[2] = (acc2[mt][nt][2] + b[2] + bf16_to_f32(r1[nt].y & 0xffff)) * s1 + s2 * bf16_to_f32(r2[nt].y & 0xffff);
-      v[3] = (acc2[mt][nt][3] + b[3] + bf16_to_f32(r1[nt].y >> 16)) * s1 + s2 * bf16_to_f32(r2[nt].y >> 16);
-      *(uint2*)(p.out + (long)m * p.ldo + nb + nt * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      for (int i = 0; i < ECH; ++i) { q1[(mt + 1) & 1][i] = fetch(p.R1, p.ldr1, mt + 1, i); q2[(mt + 1) & 1][i] = fetch(p.R2, p.ldr2, mt + 1, i); }
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < ECH; ++i) {
+      if (!e_ok(i, mt)) continue;
+      const long m = erow0 + mt * 16 + e_row[i];
+      const int n = ecol0 + e_col[i];
+      const f32x4 lo = *(const f32x4*)(slab + e_lds[i]), hi = *(const f32x4*)(slab + e_lds[i] + 16);
+      const f32x4 b0 = *(const f32x4*)(p.b2 + n), b1 = *(const f32x4*)(p.b2 + n + 4);
+      const int grp = (p.a1 || p.a2) ? (int)(m / p.rpg) : 0;
+      const float s1 = p.a1 ? p.a1[grp] : 1.0f;
+      const float s2 = p.a2 ? p.a2[grp] : 1.0f;
+      const u32x4 r1 = q1[mt & 1][i], r2 = q2[mt & 1][i];
+      float v[8] = {lo[0] + b0[0], lo[1] + b0[1], lo[2] + b0[2], lo[3] + b0[3], hi[0] + b1[0], hi[1] + b1[1], hi[2] + b1[2], hi[3] + b1[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[2 * j] = (v[2 * j] + __uint_as_float(r1[j] << 16)) * s1 + s2 * __uint_as_float(r2[j] << 16);
+        v[2 * j + 1] = (v[2 * j + 1] + __uint_as_float(r1[j] & 0xffff0000u)) * s1 + s2 * __uint_as_float(r2[j] & 0xffff0000u);
+      }
+      const u32x4 pk = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      unsigned short* op = p.out + m * p.ldo + n;
+      if (o16) *(u32x4*)op = pk;
+      else { *(u32x2*)op = u32x2{pk[0], pk[1]}; *(u32x2*)(op + 4) = u32x2{pk[2], pk[3]}; }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 #endif
 }
