@@ -240,13 +240,29 @@ def main():
     if use_dist and world > 1 and not a.no_clip_parallel:
         # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
         # single 16/32-view clip faster: CFG pair x frame<->space groups, all collectives over RCCL
+        # ... and never lose the headline line to it: a Python error is caught, and a watchdog prints the line and ends the
+        # process if the leg does not come back (a stuck collective cannot be interrupted from Python)
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["clip_parallel"] = {"error": "timed out (watchdog); headline numbers above are unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(max(90.0, 40.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
+        wd.daemon = True
+        wd.start()
         try:
             out["clip_parallel"] = clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, ms_per_step)
-        except Exception as e:            # never lose the headline line to the optional leg
+        except Exception as e:
             out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+        wd.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
+        if "error" in out.get("clip_parallel", {}):
+            sys.stdout.flush()
+            os._exit(0)                  # ranks may have diverged inside the optional leg: do not wait on a teardown barrier
         torch.distributed.destroy_process_group()
 
 
