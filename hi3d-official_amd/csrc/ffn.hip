@@ -287,6 +287,10 @@ __global__ __launch_bounds__(FNW * 64, 2) void ffn_geglu_c320_kernel(const FfnPa
 
 }  // namespace
 
+int hi3d_ffn2_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                     const void* r1, const void* r2, const float* a1, const float* a2, void* out,
+                     int32_t M, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2, int32_t rows_per_group, void* stream);
+
 extern "C" int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                               const void* r1, const void* r2, const float* a1, const float* a2, void* out,
                               int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
@@ -300,6 +304,12 @@ extern "C" int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, co
   if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2) & 15) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu: x / w1 / w2 not 16-byte aligned");
   if (((uintptr_t)out | (uintptr_t)r1 | (uintptr_t)r2) & 7) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu: out / residuals not 8-byte aligned");
   if (((uintptr_t)b1 | (uintptr_t)b2) & 15) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu: biases not 16-byte aligned");
+  // second form (ffn2.hip: 32 rows per wave with X in registers, ping-pong phases, software-pipelined GELU) unless HI3D_FFN_V=1
+  {
+    const char* e = getenv("HI3D_FFN_V");
+    if (!e || atoi(e) != 1)
+      return hi3d_ffn2_launch(x, w1, b1, w2, b2, r1, r2, a1, a2, out, M, ldx, ldo, ldr1, ldr2, rows_per_group, stream);
+  }
   FfnParams p;
   p.X = (const char*)x; p.W1 = (const char*)w1; p.b1 = b1; p.W2 = (const char*)w2; p.b2 = b2;
   p.R1 = (const unsigned short*)r1; p.R2 = (const unsigned short*)r2; p.a1 = a1; p.a2 = a2;
