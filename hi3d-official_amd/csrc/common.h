@@ -71,6 +71,16 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
+// 8-byte LDS store that the compiler does not order against in-flight LDS-DMA.  The waitcnt pass puts `s_waitcnt vmcnt(0)`
+// in front of every ds_write while `buffer_load ... lds` requests are outstanding (it cannot tell that the DMA targets and
+// the store are different slabs) -- which drains a kernel's whole weight pipeline at each such store.  Kernels that keep
+// streams in flight across a store use this form and retire it with their own `s_waitcnt lgkmcnt(0)` before the barrier.
+__device__ __forceinline__ void lds_store_b64_nodrain(void* lds_ptr, unsigned int lo, unsigned int hi) {
+  typedef unsigned int u2_ __attribute__((ext_vector_type(2)));
+  const unsigned int a = (unsigned int)(__UINTPTR_TYPE__)(LDS_AS char*)lds_ptr;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(u2_{lo, hi}) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

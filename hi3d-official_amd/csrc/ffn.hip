@@ -195,7 +195,7 @@ __global__ __launch_bounds__(FNW * 64, 2) void ffn_geglu_c320_kernel(const FfnPa
         const hi3d_f2 gl = gelu_erf_f2(hi3d_f2{v[2], v[3]});
         u[nt] = pack_bf16x2(v[0] * gl[0], v[1] * gl[1]);
       }
-      *(uint2*)(hg_w + mt * 2048) = make_uint2(u[0], u[1]);
+      lds_store_b64_nodrain(hg_w + mt * 2048, u[0], u[1]);      // (a plain store would drain the weight streams: common.h)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                // hg visible (no vmcnt drain: the weight streams stay in flight)

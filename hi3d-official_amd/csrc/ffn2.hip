@@ -7,24 +7,26 @@
 // measurements showed: the first form runs its MFMAs at 37 % utilisation because all 8 waves move in lock step through
 // 16-MFMA K steps separated by barriers -- both waves of a SIMD wait for LDS together, then both compute, then both do
 // their GELU.  Here
-//   * a wave owns 32 rows and keeps ALL of its X tile in registers (80): the first GEMM reads only weights from LDS
-//     and the 48 KiB of X slabs are gone;
-//   * the 64-column chunk of the hidden dimension is cut into six phases of 20 MFMAs,
-//         [load segment: fragment reads, a slice of GELU, LDS-DMA requests] s_barrier [20 MFMAs] s_barrier,
-//     and waves 4..7 (rows 64..127: their hg rows are their own) run one barrier behind waves 0..3, so on every SIMD
-//     one wave is in its MFMA segment while the other reads fragments / evaluates GELU;
-//   * the chunk is software-pipelined so that no phase is GELU only: the second half of a chunk's GELU and the second
-//     half of its down-projection ride in the first three phases of the NEXT chunk,
-//         Ph1  W1A(c) k 0-159   x X -> acc1A        | GELU_B(c-1) rows 0-15   -> hgB
-//         Ph2  W1A(c) k 160-319 x X -> acc1A        | GELU_B(c-1) rows 16-31  -> hgB
-//         Ph3  hgB(c-1) x W2(c-1)[:, 32:64] -> acc2 | GELU_A(c)   rows 0-15   -> hgA     request W1A(c+1)
-//         Ph4  W1B(c) k 0-159   x X -> acc1B        | GELU_A(c)   rows 16-31  -> hgA     request W2(c)[:, 32:64]
-//         Ph5  W1B(c) k 160-319 x X -> acc1B
-//         Ph6  hgA(c)   x W2(c)[:, 0:32]    -> acc2 |                                    request W1B(c+1)
-//     (A / B: the first / second 32 hidden columns of the chunk = its first / second 64 packed W1 rows.)
-// LDS: W1A 40 KiB + W1B 40 KiB (five 8 KiB K slabs each, the swizzled stage layout of gemm.hip) + the two 32-column
-// halves of the chunk's W2 slab 20 + 20 KiB + hg 16 KiB + the bias vector 10 KiB = 146 KiB.  All waits are counted vmcnt's, all barriers raw.
-// Operand layouts (packed GEGLU rows, K-major W2) are those of ffn.hip / gemm.hip: the packed weights are shared.
+//   * a wave owns 32 rows x 160 output columns and keeps 9/10 of its X rows in registers (72; the last 32 channels sit
+//     in an 8 KiB LDS slab): the first GEMM reads almost only weights from LDS and the 48 KiB of X slabs are gone;
+//   * the loop runs over HALF chunks (32 hidden columns = 64 packed W1 rows) in three phases of 20 MFMAs,
+//         [load segment: first fragments, a slice of GELU, LDS-DMA requests and their waits] s_barrier
+//         [compute segment: 20 MFMAs + the rolling fragment reads] s_barrier,
+//     two for the first GEMM (K halves) and one for the down-projection of the PREVIOUS half chunk; every code site
+//     exists once, so the accumulators stay in place (two sites for the second GEMM cost a rotating copy of the
+//     80-register output tile and spilled);
+//   * waves 4..7 (rows 64..127: their hg rows are their own) run one barrier behind waves 0..3, so on every SIMD one
+//     wave is in a compute segment while the other does its loads, GELU and DMA requests;
+//   * the first GEMM's accumulators start from the bias; hg is stored with an LDS store the compiler does not drain
+//     the weight streams for (common.h: lds_store_b64_nodrain -- the first form waited vmcnt(0) in every chunk).
+// Measured (profiles/r02d_*): 1.50 ms at M = 524288 (860 TFLOP/s) against 1.54 ms for the first form; the ablations
+// (r02d_ffn2_ablation_v1.log) put the limit at the non-MFMA issue work per SIMD -- GELU ~700, DMA requests ~550,
+// fragment reads ~600 cycles per wave and half chunk beside 966 cycles of MFMA -- and at the exposed prologue /
+// epilogue of a kernel that fits one block per CU (~15 %).
+// LDS: two W1 slots of 40 KiB (five 8 KiB K slabs each, the swizzled stage layout of gemm.hip) + two W2 slots of 20 KiB
+// (320 rows x 32 hidden columns) + hg 16 KiB + the bias vector 10 KiB + the X slab 8 KiB = 154 KiB.  All waits are
+// counted vmcnt's, all barriers raw.  Operand layouts (packed GEGLU rows, K-major W2) are those of ffn.hip / gemm.hip:
+// the packed weights are shared.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -49,9 +51,9 @@ constexpr int W1S = 5 * 8192;              // one W1 stage: 64 packed rows x 320
 constexpr int W2H = 320 * 64;              // half of a chunk's W2 slab: 320 rows x 32 k, 64-byte rows
 constexpr int HGB = GBM * 128;             // hg: 128 rows x 64 hidden
 constexpr int B1B = 8 * GC * 4;            // the packed first-layer bias, fp32 (read in every GELU slice: no VMEM loads inside the loop)
-constexpr int FFN2_LDS = 2 * W1S + 2 * W2H + HGB + B1B;      // 149,504 B
-constexpr int W1_OPS = 5;                  // LDS-DMA instructions per wave and W1 stage
-constexpr int W2_OPS_MIN = 2;              // ... per W2 half: waves 0-3 issue 3, waves 4-7 issue 2
+constexpr int X9B = GBM * 64;              // the last 32 channels of the X tile (k = 288..319): the 80 registers of a whole X tile, the
+                                           // output tile (80) and the rest do not fit in 256 -- 9 of the 10 half K steps stay in registers
+constexpr int FFN2_LDS = 2 * W1S + 2 * W2H + HGB + B1B + X9B;      // 157,696 B
 
 __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Params p) {
 #if __HIP_DEVICE_COMPILE__
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   char* const sW2 = smem + 2 * W1S;                         // k 0..31 half at 0, k 32..63 half at W2H
   char* const sHG = sW2 + 2 * W2H;
   float* const sB1 = (float*)(sHG + HGB);
+  char* const sX9 = (char*)sB1 + B1B;                       // [mt][32-row block][lane] x 16 B: fragments of k = 288..319, shared by the two column halves
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,13 +76,15 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // ---- X: the wave's 32 rows, all 320 channels, in MFMA B-operand layout (lane (fr, fg): row fr of each 16-row block,
   // k = 32*kk + 8*fg .. +7)
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)m0 * p.ldx * 2), 0, 0x7fffffff, 0x00020000);
-  bf16x8 xr[10][2];
+  bf16x8 xr[9][2];
+  const int x9_off = wmg * 1024 + lane * 16;                // + mt * 4096
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int r = wmg * 32 + mt * 16 + fr;
     const unsigned vo = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + fg * 16) : INV;
 #pragma unroll
-    for (int kk = 0; kk < 10; ++kk) xr[kk][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0));
+    for (int kk = 0; kk < 9; ++kk) xr[kk][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0));
+    if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
   }
 
   // ---- weight loaders.  W1 stage = 40 pieces of 1 KiB (8 packed rows x 128 B of one K slab): wave w moves row group w
@@ -92,26 +97,33 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     const int fi = (jw >> 3) * 4 + (jw & 3);                 // MFMA row index that reads it
     w1_voff = (unsigned)(j * GC * 2 + ((lslot ^ ((fi >> 1) & 7)) << 4));
   }
+  // W2 rows are 64 B (4 chunks of 16 B): the 16 lanes of a ds_read_b128 lane group hold two k groups fg and, per fg, two
+  // row quads q = fr >> 2 -- {0,3} or {1,2} -- whose rows sit 40 apart (a multiple of 4 rows = 256 B: the same banks).
+  // Chunk g of a row of quad q is stored at position g ^ ((4 - q) & 3): every lane group then covers 16 distinct
+  // (row mod 4, position) pairs.  q differs between a wave's three pieces: three lane offsets.
   unsigned w2_voff[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) w2_voff[i] = (unsigned)(((w + 8 * i) * 16 + (lane >> 2)) * GH * 2 + (lane & 3) * 16);
-  auto issue_w1 = [&](int c, int stage) {                    // stage 0 = A (packed rows 128c .. +63), 1 = B
-    const int soff = (c * 128 + stage * 64) * GC * 2;
+  for (int i = 0; i < 3; ++i) {
+    const int r = (w + 8 * i) * 16 + (lane >> 2), q = (r % 160) / 40;
+    w2_voff[i] = (unsigned)(r * GH * 2 + (((lane & 3) ^ ((4 - q) & 3)) << 4));
+  }
+  auto issue_w1 = [&](int hc, int slot) {                   // packed rows 64 hc .. +63 (half chunk hc) -> W1 slot
+    const int soff = hc * 64 * GC * 2;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (LDS_AS void*)(sW1 + stage * W1S + i * 8192 + w * 1024), 16, w1_voff, soff + i * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (LDS_AS void*)(sW1 + slot * W1S + i * 8192 + w * 1024), 16, w1_voff, soff + i * 128, 0, 0);
   };
-  auto issue_w2 = [&](int c, int half) {                     // hidden columns 64c + 32 half .. +31 of every W2 row
+  auto issue_w2 = [&](int hc, int slot) {                   // hidden columns 32 hc .. +31 of every W2 row -> W2 slot
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (w + 8 * i < 20)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (LDS_AS void*)(sW2 + half * W2H + (w + 8 * i) * 1024), 16, w2_voff[i], c * 128 + half * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (LDS_AS void*)(sW2 + slot * W2H + (w + 8 * i) * 1024), 16, w2_voff[i], hc * 64, 0, 0);
   };
 
   // ---- fragment read offsets
   const int f_sw = (fr >> 1) & 7;
   const int w1_off = (wn * 32 + (fr >> 2) * 8 + (fr & 3)) * 128;                  // + nt * 512, + slab * 8192
-  const int w2_off = (wn * 160 + (fr >> 2) * 40 + (fr & 3)) * 64 + fg * 16;       // + nt * 256   (64-byte rows, linear)
+  const int w2_off = (wn * 160 + (fr >> 2) * 40 + (fr & 3)) * 64 + ((fg ^ ((4 - (fr >> 2)) & 3)) << 4);   // + nt * 256   (64-byte rows)
   const int hg_off = (wmg * 32 + fr) * 128;                                        // + mt * 2048, + swizzled chunk
   // this lane's packed columns of a stage: wn*32 + fg*8 + nt*4 .. +3  (= stage-local hidden columns wn*16 + fg*4 + nt*2, +1)
   const float* b1p = sB1 + wn * 32 + fg * 8;
@@ -125,53 +137,78 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 acc1a[2][2], acc1b[2][2];
+  f32x4 acc1[2][2];
 
   // value * gelu(gate) of one 16-row block of a stage's accumulators -> 4 hidden columns per lane -> hg
-  auto gelu_store = [&](const f32x4 (&acc)[2][2], int c, int stage, int mt) {
+  auto gelu_store = [&](const f32x4 (&acc)[2][2], int stage, int mt) {
     unsigned int u[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const f32x4 b = *(const f32x4*)(b1p + (c * 128 + stage * 64) + nt * 4);
-      f32x4 v = acc[mt][nt];
-      v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+      const f32x4 v = acc[mt][nt];
       const hi3d_f2 gl = gelu_erf_f2(hi3d_f2{v[2], v[3]});
       u[nt] = pack_bf16x2(v[0] * gl[0], v[1] * gl[1]);
     }
-    *(uint2*)hg_wptr(stage, mt) = make_uint2(u[0], u[1]);
+    lds_store_b64_nodrain(hg_wptr(stage, mt), u[0], u[1]);      // (a plain store would drain the weight streams: common.h)
   };
-  // first GEMM, one phase: 5 of the 10 half K steps of a stage
-  auto g1_read = [&](bf16x8 (&wf)[5][2], int stage, int half) {
+  // first GEMM, one phase: 5 of the 10 half K steps of a stage.  Two of the five fragment pairs are read in the load
+  // segment; every later pair is requested into the registers of the pair just issued to the matrix core (4 MFMAs ahead
+  // of its use) -- all five at once do not fit beside X and the output tile.
+  auto g1_frag = [&](bf16x8 (&f)[2], int stage, int kk) {
+    const char* s = sW1 + stage * W1S + (kk >> 1) * 8192 + w1_off + ((((kk & 1) * 4 + fg) ^ f_sw) << 4);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int kk = half * 5 + q;
-      const char* s = sW1 + stage * W1S + (kk >> 1) * 8192 + w1_off + ((((kk & 1) * 4 + fg) ^ f_sw) << 4);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) wf[q][nt] = *(const bf16x8*)(s + nt * 512);
-    }
+    for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(s + nt * 512);
   };
-  auto g1_mfma = [&](const bf16x8 (&wf)[5][2], f32x4 (&acc)[2][2], int half) {
+  auto g1_read = [&](bf16x8 (&wf)[2][2], int stage, int half) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q][nt], xr[half * 5 + q][mt],
-                                                                  (half == 0 && q == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mt][nt], 0, 0, 0);
+    for (int q = 0; q < 2; ++q) g1_frag(wf[q], stage, half * 5 + q);
   };
-  // second GEMM, one phase: K half `kh` (32 hidden columns) of the chunk whose hg half is ready
-  auto g2_read = [&](bf16x8 (&xf)[2], bf16x8 (&wf)[10], int kh) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) xf[mt] = *(const bf16x8*)(sHG + hg_off + mt * 2048 + (((kh * 4 + fg) ^ f_sw) << 4));
-#pragma unroll
-    for (int nt = 0; nt < 10; ++nt) wf[nt] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + nt * 256);
-  };
-  auto g2_mfma = [&](const bf16x8 (&xf)[2], const bf16x8 (&wf)[10]) {
+  auto g1_step = [&](const bf16x8 (&f)[2], f32x4 (&acc)[2][2], int kk, const bf16x8 (&x9)[2], const f32x4 (&bias)[2]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 10; ++nt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc2[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < 2; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[nt], kk < 9 ? xr[kk < 9 ? kk : 0][mt] : x9[mt],
+                                                                kk == 0 ? bias[nt] : acc[mt][nt], 0, 0, 0);
+  };
+  auto g1_mfma = [&](bf16x8 (&wf)[2][2], f32x4 (&acc)[2][2], int stage, int half, const f32x4 (&bias)[2]) {
+    const int k0 = half * 5;
+    bf16x8 x9[2];
+    if (half == 1) {                               // the X fragments of the last half K step (requested three steps ahead of their use)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) x9[mt] = *(const bf16x8*)(sX9 + mt * 4096 + x9_off);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      g1_step(wf[q & 1], acc, k0 + q, x9, bias);
+      if (q + 2 < 5) {                             // this pair's registers take the pair two steps ahead
+        __builtin_amdgcn_sched_barrier(0);
+        g1_frag(wf[q & 1], stage, k0 + q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the late fragment reads are retired before the closing barrier)
+  };
+  // second GEMM, one phase: K half `kh` (32 hidden columns) of the chunk whose hg half is ready.  The ten W2 fragments
+  // do not fit beside X and the output tile: three are read in the load segment, the others into the registers of the
+  // fragment just issued, three column blocks (6 MFMAs) ahead of their use.
+  auto g2_read = [&](bf16x8 (&xf)[2], bf16x8 (&wf)[3], int kh) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xf[mt] = *(const bf16x8*)(sHG + hg_off + mt * 2048 + (((kh * 4 + fg) ^ f_sw) << 4));
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) wf[nt] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + nt * 256);
+  };
+  auto g2_mfma = [&](const bf16x8 (&xf)[2], bf16x8 (&wf)[3], int kh) {
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt % 3], xf[mt], acc2[mt][nt], 0, 0, 0);
+      if (nt + 3 < 10) {                           // this fragment's registers take the one three column blocks ahead
+        __builtin_amdgcn_sched_barrier(0);
+        wf[nt % 3] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + (nt + 3) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the late fragment reads are retired before the closing barrier)
   };
   auto seg_end = [&]() {                          // end of a load segment: fragment reads / hg writes retired, then the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -185,88 +222,75 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: the bias vector and both W1 stages of chunk 0
+  // ---- prologue: the bias vector and the first W1 stage
   for (int i = tid; i < 8 * GC / 4; i += 512) *(f32x4*)(sB1 + i * 4) = *(const f32x4*)(p.b1 + i * 4);
-  issue_w1(0, 0); issue_w1(0, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue_w1(0, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the bias copy and the X slab are plain LDS stores)
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();          // the stagger
 
-  for (int c = 0; c <= GNCH; ++c) {
-    const bool cur = c < GNCH, prev = c > 0;       // this chunk's first GEMM exists / the previous chunk's second half is pending
+  // One loop iteration = one HALF chunk hc (32 hidden columns = 64 packed W1 rows; slot s = hc & 1 of every ring).
+  // Compute segments hold MFMAs and their rolling fragment reads only; everything else sits in the load segments, under
+  // the other group's MFMAs:
+  //     Ph1  load: GELU(hc-1) rows 16-31 -> hg half s^1; bias, fragments
+  //          compute: W1(hc) k 0-159 x X -> acc1 (from the bias)
+  //     Ph2  load: wait W2(hc-1); request W1(hc+1) -> W1 slot s^1; fragments
+  //          compute: W1(hc) k 160-319 x X -> acc1
+  //     Ph3  load: wait W1(hc+1); request W2(hc) -> W2 slot s; GELU(hc) rows 0-15 -> hg half s; fragments of hg half s^1 / W2(hc-1)
+  //          compute: hg half s^1 x W2(hc-1) -> acc2 (the previous half chunk)
+  // Ring protocol.  A phase reads LDS in its load segment AND (the rolling fragments) in its compute segment, and the
+  // late group runs one barrier behind: the last read of phase k happens in the slot in which the early group already
+  // executes the load segment of phase k+1.  So the request that overwrites what phase k read is issued in the load
+  // segment of phase k+2 at the earliest, and a wave waits for its own pieces in the load segment one phase before the
+  // first reader (the other group reads one barrier later).  hg rows belong to one group (both column halves of a
+  // 32-row block are in the same half of the block), so its hazards are plain program order plus any barrier.
+  constexpr int NHC = 2 * GNCH;
+  for (int hc = 0; hc <= NHC; ++hc) {
+    const bool cur = hc < NHC, prev = hc > 0;
+    const int sl = hc & 1;
     // ---- Ph1
     {
-      bf16x8 wf[5][2];
-      if (cur) { issue_w2(c, 0); g1_read(wf, 0, 0); }
-      if (prev) gelu_store(acc1b, c - 1, 1, 0);
+      bf16x8 wf[2][2];
+      f32x4 bias[2];
+      if (cur) {
+        g1_read(wf, sl, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bias[nt] = *(const f32x4*)(b1p + hc * 64 + nt * 4);
+      }
+      if (prev) gelu_store(acc1, sl ^ 1, 1);
       seg_end();
-      if (cur) g1_mfma(wf, acc1a, 0);
+      if (cur) g1_mfma(wf, acc1, sl, 0, bias);
       cseg_end();
     }
-    // ---- Ph2
-    {
-      bf16x8 wf[5][2];
-      if (prev) {                                  // W2(c-1)[:, 32:64] (requested in Ph4 of the previous chunk) has landed
-        if (cur) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_OPS + W2_OPS_MIN) : "memory");   // younger: W1B(c), W2(c)[:, 0:32]
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (cur) g1_read(wf, 0, 1);
-      if (prev) gelu_store(acc1b, c - 1, 1, 1);
+    if (cur) {
+      // ---- Ph2
+      bf16x8 wf[2][2];
+      f32x4 bias[2];                               // (unused: k > 0)
+      // W2(hc-1) (requested in the previous Ph3, read in this Ph3) has landed: nothing younger is in flight
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (hc + 1 < NHC) issue_w1(hc + 1, sl ^ 1);
+      g1_read(wf, sl, 1);
       seg_end();
-      if (cur) g1_mfma(wf, acc1a, 1);
+      g1_mfma(wf, acc1, sl, 1, bias);
       cseg_end();
     }
     // ---- Ph3
     {
-      bf16x8 xf[2], wf[10];
-      if (cur) {                                   // W1B(c) has landed (younger: W2(c)[:, 0:32]); W1A is read out: request W1A(c+1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2_OPS_MIN) : "memory");
-        if (c + 1 < GNCH) issue_w1(c + 1, 0);
+      bf16x8 xf[2], wf[3];
+      if (prev) g2_read(xf, wf, sl ^ 1);
+      if (cur) {
+        // W1(hc+1) (requested in Ph2, read from the next Ph1 on) has landed: nothing younger is in flight.  The last
+        // half chunk's W2 has its reader in the very next phase: requested and waited for here.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_w2(hc, sl);
+        if (hc + 1 == NHC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gelu_store(acc1, sl, 0);
       }
-      if (prev) g2_read(xf, wf, 1);
-      if (cur) gelu_store(acc1a, c, 0, 0);
       seg_end();
-      if (prev) g2_mfma(xf, wf);
-      cseg_end();
-    }
-    if (!cur) break;
-    // ---- Ph4
-    {
-      bf16x8 wf[5][2];
-      issue_w2(c, 1);
-      g1_read(wf, 1, 0);
-      gelu_store(acc1a, c, 0, 1);
-      seg_end();
-      g1_mfma(wf, acc1b, 0);
-      cseg_end();
-    }
-    // ---- Ph5
-    {
-      bf16x8 wf[5][2];
-      // W2(c)[:, 0:32] (requested in Ph1) has landed; younger: W1A(c+1) if it exists, W2(c)[:, 32:64]
-      if (c + 1 < GNCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_OPS + W2_OPS_MIN) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2_OPS_MIN) : "memory");
-      g1_read(wf, 1, 1);
-      seg_end();
-      g1_mfma(wf, acc1b, 1);
-      cseg_end();
-    }
-    // ---- Ph6
-    {
-      bf16x8 xf[2], wf[10];
-      if (c + 1 < GNCH) {                          // W1A(c+1) has landed (younger: W2(c)[:, 32:64]); W1B is read out: request W1B(c+1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2_OPS_MIN) : "memory");
-        issue_w1(c + 1, 1);
-      }
-      g2_read(xf, wf, 0);
-      seg_end();
-      g2_mfma(xf, wf);
+      if (prev) g2_mfma(xf, wf, sl ^ 1);
       cseg_end();
     }
   }
-  if (!late) __builtin_amdgcn_s_barrier();         // the leading half catches the stagger up
-  __syncthreads();                                 // every wave is done with the slabs
-
   // ---- epilogue: every wave stages its 32 x 160 tile, 16 rows at a time, through a private fp32 slab and issues its
   // residual loads / stores row-contiguous, 16 bytes per lane (as the wide GEMM tiles do)
   constexpr int EW = 160, EROW = EW * 4 + 16, ESLAB = 16 * EROW, ECPR = EW / 8, ECH = (16 * ECPR + 63) / 64;   // 5 chunks per lane and pass
@@ -275,40 +299,39 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   const int ecol0 = wn * EW;
   const long erow0 = (long)m0 + wmg * 32;
   const int rows_left = p.M - (int)erow0;
-  int e_row[ECH], e_col[ECH];
-#pragma unroll
-  for (int i = 0; i < ECH; ++i) {
-    const int cidx = lane + 64 * i;
-    e_row[i] = cidx / ECPR;
-    e_col[i] = (cidx - e_row[i] * ECPR) * 8;
-  }
-  auto e_ok = [&](int i, int mt) { return e_row[i] + mt * 16 < rows_left; };
+  auto e_row_ = [&](int i) { return (lane + 64 * i) / ECPR; };          // (recomputed at every use: the loop above left no registers to park them in)
+  auto e_col_ = [&](int i) { return ((lane + 64 * i) % ECPR) * 8; };
+  auto e_ok = [&](int i, int mt) { return e_row_(i) + mt * 16 < rows_left; };
   auto fetch = [&](const unsigned short* R, int ldr, int mt, int i) -> u32x4 {
     if (!R || !e_ok(i, mt)) return u32x4{0u, 0u, 0u, 0u};
-    const unsigned short* rp = R + (erow0 + mt * 16 + e_row[i]) * ldr + ecol0 + e_col[i];
+    const unsigned short* rp = R + (erow0 + mt * 16 + e_row_(i)) * ldr + ecol0 + e_col_(i);
     if ((ldr & 7) == 0 && (((uintptr_t)R) & 15) == 0) return *(const u32x4*)rp;
     const u32x2 lo = *(const u32x2*)rp, hi = *(const u32x2*)(rp + 4);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
   };
-  const bool o16 = (p.ldo & 7) == 0 && (((uintptr_t)p.out) & 15) == 0;
+  // the residual tiles are requested before the closing barriers (the X registers are dead by now): their latency
+  // passes under the barriers and the first slab pass
   u32x4 q1[2][ECH], q2[2][ECH];
 #pragma unroll
-  for (int i = 0; i < ECH; ++i) { q1[0][i] = fetch(p.R1, p.ldr1, 0, i); q2[0][i] = fetch(p.R2, p.ldr2, 0, i); }
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < ECH; ++i) { q1[mt][i] = fetch(p.R1, p.ldr1, mt, i); q2[mt][i] = fetch(p.R2, p.ldr2, mt, i); }
+  if (!late) __builtin_amdgcn_s_barrier();         // the leading half catches the stagger up
+  __builtin_amdgcn_s_barrier();                    // every wave is done with the slabs (their reads were retired in the loop;
+                                                   // a __syncthreads() would also wait for the residual tiles just requested)
+
+  const bool o16 = (p.ldo & 7) == 0 && (((uintptr_t)p.out) & 15) == 0;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) *(f32x4*)(slab + fr * EROW + (fg * 40 + nt * 4) * 4) = acc2[mt][nt];
-    if (mt + 1 < 2) {
-#pragma unroll
-      for (int i = 0; i < ECH; ++i) { q1[1][i] = fetch(p.R1, p.ldr1, 1, i); q2[1][i] = fetch(p.R2, p.ldr2, 1, i); }
-    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < ECH; ++i) {
       if (!e_ok(i, mt)) continue;
-      const long m = erow0 + mt * 16 + e_row[i];
-      const int n = ecol0 + e_col[i];
-      const char* sp = slab + e_row[i] * EROW + e_col[i] * 4;
+      const long m = erow0 + mt * 16 + e_row_(i);
+      const int n = ecol0 + e_col_(i);
+      const char* sp = slab + e_row_(i) * EROW + e_col_(i) * 4;
       const f32x4 lo = *(const f32x4*)sp, hi = *(const f32x4*)(sp + 16);
       const f32x4 b0 = *(const f32x4*)(p.b2 + n), b1 = *(const f32x4*)(p.b2 + n + 4);
       const int grp = (p.a1 || p.a2) ? (int)(m / p.rpg) : 0;

@@ -180,6 +180,34 @@ def test_ffn_geglu_fused(dev, M, blend):
         ops.ffn_geglu(x.to(dev), w1p.to(dev), b1p.to(dev), pack_linear(w2).to(dev), b2.to(dev), M=M, C=640)
 
 
+@pytest.mark.parametrize("blend", [False, True])
+def test_ffn_geglu_race_screen(dev, blend, monkeypatch):
+    """The fused feed-forward keeps weight rings, an hg slab and two staggered wave groups in step with counted waits
+    and raw barriers only: many blocks per CU, twelve launches -- the outputs must be bitwise repeatable (a ring read
+    before its data landed, or overwritten too early, shows up as run-to-run differences), and the two forms of the
+    kernel (HI3D_FFN_V=1: the lock-step first form) must agree to rounding."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_geglu, pack_linear
+    C, rpg, M = 320, 4096, 128 * 256 * 5 + 77
+    G = (M + rpg - 1) // rpg
+    x = bf(rnd((M, C), 131)).to(dev)
+    w1, b1 = bf(rnd((8 * C, C), 132, C ** -0.5)).float(), rnd((8 * C,), 133)
+    w2, b2 = bf(rnd((C, 4 * C), 134, (4 * C) ** -0.5)).float(), rnd((C,), 135)
+    R1, R2 = bf(rnd((M, C), 136)).to(dev), bf(rnd((M, C), 137)).to(dev)
+    kw = dict(R2=R2, a1=(rnd((G,), 138).abs() + 0.5).to(dev), a2=rnd((G,), 139).to(dev), rows_per_group=rpg) if blend else {}
+    w1p, b1p = pack_geglu(w1, b1)
+    w1p, b1p, w2p, b2 = w1p.to(dev), b1p.to(dev), pack_linear(w2).to(dev), b2.to(dev)
+    run = lambda: ops.ffn_geglu(x, w1p, b1p, w2p, b2, M=M, C=C, R1=R1, **kw)
+    first = run()
+    for _ in range(11):
+        assert torch.equal(run(), first)
+    monkeypatch.setenv("HI3D_FFN_V", "1")
+    other = run()
+    for _ in range(3):
+        assert torch.equal(run(), other)
+    assert relerr(first, other.float()) < 4e-3
+
+
 @pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
                                                          (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
                                                          (2, 9, 9, 64, 64, 2, 0)])
