@@ -10,7 +10,10 @@ class VideoDecoder(Decoder):
 
     def __init__(self, *args, video_kernel_size=3, alpha=0.0, merge_strategy="learned", time_mode="conv-only", **kwargs):
         if time_mode != "conv-only":
-            raise NotImplementedError(f"VideoDecoder time_mode={time_mode} (only 'conv-only' is built)")
+            # the reference cannot construct these either: _make_attn hands the function make_time_attn to partialclass,
+            # which subclasses it -> TypeError (temporal_ae.py:326, sgm/util.py:99)
+            raise NotImplementedError(f"VideoDecoder time_mode={time_mode} (only 'conv-only' is built; the reference "
+                                      "raises TypeError when constructing the other modes)")
         if isinstance(video_kernel_size, int) or list(video_kernel_size) != [3, 1, 1]:
             raise NotImplementedError("VideoDecoder needs video_kernel_size [3, 1, 1]")
         if merge_strategy != "learned":
