@@ -472,3 +472,132 @@ def aes_embedder(sd, video, heads=16, clip_prefix="aesthetic_model.visual.", mlp
     for i in (0, 2, 4, 6, 7):
         f = F.linear(f, sd[mlp_prefix + f"{i}.weight"], sd[mlp_prefix + f"{i}.bias"])
     return torch.cat([f, sinusoid(f[:, 0] * 100, 255)], dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# depth conditioner (stage-2 / v02): MiDaS DPT-hybrid, then min-max normalisation and a 3x3 pixel-unshuffle
+# --------------------------------------------------------------------------------------
+# PARITY PIN: the DPT side (hooks, readout projection, reassemble, fusion, head) restates the reference's vendored
+# annotator/midas/{vit,blocks,dpt_depth}.py and is pinned against THAT code (tests/golden/dpt_hybrid_64x96.pt,
+# oracle/gen_golden_dpt.py).  The backbone is timm's `vit_base_resnet50_384` (annotator/midas/vit.py:499; timm is a
+# pip dependency, absent from /root/reference and from this container): restated from the published BiT-ResNetV2 /
+# ViT architecture, and pinned against HuggingFace's independent DPTForDepthEstimation(is_hybrid=True) with its own
+# BiT backbone (8.8e-5 on shared weights, gen_golden_dpt.py --check-hf) -- "parity unpinned" against timm proper.
+def _tf_same_pad(x, k, s, value=0.0):
+    ih, iw = x.shape[-2:]
+    ph = max((-(-ih // s) - 1) * s + k - ih, 0)
+    pw = max((-(-iw // s) - 1) * s + k - iw, 0)
+    return F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=value) if (ph or pw) else x
+
+
+def _std_conv(sd, p, x, stride=1):
+    """timm StdConv2dSame(eps=1e-8): per-output-channel weight standardisation (biased variance); symmetric padding at
+    stride 1, TensorFlow 'SAME' (the odd unit after) otherwise."""
+    w = sd[p + ".weight"]
+    k = w.shape[-1]
+    w = (w - w.mean(dim=(1, 2, 3), keepdim=True)) / torch.sqrt(w.var(dim=(1, 2, 3), keepdim=True, unbiased=False) + 1e-8)
+    if stride != 1:
+        return F.conv2d(_tf_same_pad(x, k, stride), w, None, stride)
+    return F.conv2d(x, w, None, 1, (k - 1) // 2)
+
+
+def _gn32(sd, p, x, relu):
+    x = F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    return F.relu(x) if relu else x
+
+
+def _bit_stage(sd, p, x, stride, depth):
+    """BiT bottlenecks, non-pre-activation: conv1x1-GN-ReLU, conv3x3(stride)-GN-ReLU, conv1x1-GN, + shortcut
+    (first block: conv1x1(stride)-GN), ReLU."""
+    for b in range(depth):
+        q = f"{p}.blocks.{b}"
+        st = stride if b == 0 else 1
+        sc = _gn32(sd, q + ".downsample.norm", _std_conv(sd, q + ".downsample.conv", x, st), False) if b == 0 else x
+        h = _gn32(sd, q + ".norm1", _std_conv(sd, q + ".conv1", x), True)
+        h = _gn32(sd, q + ".norm2", _std_conv(sd, q + ".conv2", h, st), True)
+        h = _gn32(sd, q + ".norm3", _std_conv(sd, q + ".conv3", h), False)
+        x = F.relu(h + sc)
+    return x
+
+
+def dpt_hybrid(sd, x, prefix="model.model.", heads=12, return_layers=False):
+    """DPTDepthModel(backbone='vitb_rn50_384', non_negative=True).forward (annotator/midas/dpt_depth.py:60-106):
+    x fp32 [B,3,H,W], H and W multiples of 32 -> inverse depth [B,H,W]."""
+    g = lambda k: sd[prefix + k]
+    sub = lambda p: {k[len(prefix + p):]: v for k, v in sd.items() if k.startswith(prefix + p)}
+    B, _, H, W = x.shape
+    # ---- backbone (timm VisionTransformer with HybridEmbed; forward_flex, annotator/midas/vit.py:126-160)
+    bb = sub("pretrained.model.patch_embed.backbone.")
+    h = _gn32(bb, "stem.norm", _std_conv(bb, "stem.conv", x, 2), True)
+    h = F.max_pool2d(_tf_same_pad(h, 3, 2, -float("inf")), 3, 2)
+    l1 = _bit_stage(bb, "stages.0", h, 1, 3)                         # hook '1': 256 ch, H/4
+    l2 = _bit_stage(bb, "stages.1", l1, 2, 4)                        # hook '2': 512 ch, H/8
+    l3 = _bit_stage(bb, "stages.2", l2, 2, 9)                        # 1024 ch, H/16
+    P = "pretrained.model."
+    t = F.conv2d(l3, g(P + "patch_embed.proj.weight"), g(P + "patch_embed.proj.bias")).flatten(2).transpose(1, 2)
+    gh, gw = H // 16, W // 16
+    pe = g(P + "pos_embed")
+    g0 = int(math.sqrt(pe.shape[1] - 1))
+    grid = F.interpolate(pe[0, 1:].reshape(1, g0, g0, -1).permute(0, 3, 1, 2), size=(gh, gw), mode="bilinear")
+    pe = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], dim=1)
+    t = torch.cat([g(P + "cls_token").expand(B, -1, -1), t], dim=1) + pe
+    Wd = t.shape[-1]
+    hooks = {}
+    for i in range(12):
+        p = P + f"blocks.{i}."
+        n = F.layer_norm(t, (Wd,), g(p + "norm1.weight"), g(p + "norm1.bias"), 1e-6)
+        q, k, v = F.linear(n, g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias")).chunk(3, dim=-1)
+        S, d = q.shape[1], Wd // heads
+        q, k, v = [u.reshape(B, S, heads, d).transpose(1, 2) for u in (q, k, v)]
+        a = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1) @ v
+        t = t + F.linear(a.transpose(1, 2).reshape(B, S, Wd), g(p + "attn.proj.weight"), g(p + "attn.proj.bias"))
+        n = F.layer_norm(t, (Wd,), g(p + "norm2.weight"), g(p + "norm2.bias"), 1e-6)
+        t = t + F.linear(F.gelu(F.linear(n, g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"))), g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias"))
+        if i in (8, 11):
+            hooks[i] = t
+    # ---- reassemble (vit.py:446-476): ProjectReadout -> [B, 768, gh, gw] -> conv1x1 (-> conv3x3 stride 2)
+    def readout(tok, p):
+        cls = tok[:, :1].expand(-1, tok.shape[1] - 1, -1)
+        f = F.gelu(F.linear(torch.cat([tok[:, 1:], cls], dim=-1), g(p + ".0.project.0.weight"), g(p + ".0.project.0.bias")))
+        f = f.transpose(1, 2).reshape(B, Wd, gh, gw)
+        return F.conv2d(f, g(p + ".3.weight"), g(p + ".3.bias"))
+    r3 = readout(hooks[8], "pretrained.act_postprocess3")
+    r4 = readout(hooks[11], "pretrained.act_postprocess4")
+    r4 = F.conv2d(r4, g("pretrained.act_postprocess4.4.weight"), g("pretrained.act_postprocess4.4.bias"), 2, 1)
+    layers = [l1, l2, r3, r4]
+    # ---- fusion decoder (dpt_depth.py:71-82; blocks.py:261-390): features 256, ReLU, no BN, align_corners=True
+    rn = [F.conv2d(layers[i], g(f"scratch.layer{i + 1}_rn.weight"), None, 1, 1) for i in range(4)]
+
+    def rcu(p, u):
+        o = F.conv2d(F.relu(u), g(p + ".conv1.weight"), g(p + ".conv1.bias"), 1, 1)
+        return F.conv2d(F.relu(o), g(p + ".conv2.weight"), g(p + ".conv2.bias"), 1, 1) + u
+
+    def fusion(p, a, b=None):
+        o = a if b is None else a + rcu(p + ".resConfUnit1", b)
+        o = F.interpolate(rcu(p + ".resConfUnit2", o), scale_factor=2, mode="bilinear", align_corners=True)
+        return F.conv2d(o, g(p + ".out_conv.weight"), g(p + ".out_conv.bias"))
+    path = fusion("scratch.refinenet4", rn[3])
+    path = fusion("scratch.refinenet3", path, rn[2])
+    path = fusion("scratch.refinenet2", path, rn[1])
+    path = fusion("scratch.refinenet1", path, rn[0])
+    # ---- head (dpt_depth.py:88-104)
+    o = F.conv2d(path, g("scratch.output_conv.0.weight"), g("scratch.output_conv.0.bias"), 1, 1)
+    o = F.interpolate(o, scale_factor=2, mode="bilinear", align_corners=True)
+    o = F.relu(F.conv2d(o, g("scratch.output_conv.2.weight"), g("scratch.output_conv.2.bias"), 1, 1))
+    o = F.relu(F.conv2d(o, g("scratch.output_conv.4.weight"), g("scratch.output_conv.4.bias")))
+    return (o.squeeze(1), layers) if return_layers else o.squeeze(1)
+
+
+def depth_embedder(sd, x, T=16, shuffle_size=3, scale_factor=2.6666, prefix="model.model."):
+    """DepthEmbedder.forward (vtdm/encoders.py:31-53; use_3d False): x [(b t),3,H,W] in [-1,1] -> bilinear resize to
+    the multiple of 32 below H / 2.6666 -> DPT-hybrid -> bilinear resize to (H/8*3, W/8*3) -> per-image
+    (y - min) / max(max, 1e-6) -> 'b c (h h0) (w w0) -> b (c h0 w0) h w' -> [(b t), 9, H/8, W/8]."""
+    H, W = x.shape[-2:]
+    sH, sW = int(H / scale_factor / 32) * 32, int(W / scale_factor / 32) * 32
+    y = dpt_hybrid(sd, F.interpolate(x, [sH, sW], mode="bilinear"), prefix)[:, None]
+    y = F.interpolate(y, [H // 8 * shuffle_size, W // 8 * shuffle_size], mode="bilinear")
+    y = y - y.amin(dim=(1, 2, 3), keepdim=True)
+    y = y / y.amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-6)
+    B, _, Hh, Ww = y.shape
+    s = shuffle_size
+    return y.reshape(B, 1, Hh // s, s, Ww // s, s).permute(0, 1, 3, 5, 2, 4).reshape(B, s * s, Hh // s, Ww // s)

@@ -132,3 +132,27 @@ def test_clip_visual_oracle_matches_independent_implementation(name):
     out = O.clip_visual(sd, fx["img"], c["heads"], c["act"])
     assert out.shape == fx["out"].shape
     assert rel(out, fx["out"]) < TOL
+
+
+def test_dpt_hybrid_oracle_matches_reference_midas():
+    """The depth conditioner's DPT-hybrid restatement vs the reference's vendored MiDaS code run on the timm stand-in
+    backbone (oracle/gen_golden_dpt.py); the fixture also records how far HuggingFace's independent DPT-hybrid was from
+    that run on the same weights (pins the stand-in backbone: must be fp32 noise)."""
+    fx = load("dpt_hybrid_64x96")
+    P = fx["key_prefix"]
+    sd = synth.synth_state_dict({P + k: s for k, s in fx["shapes"].items()}, fx["weight_seed"])
+    out, layers = O.dpt_hybrid(sd, fx["x"], P, return_layers=True)
+    for a, b in zip(layers, fx["layers"]):
+        assert a.shape == b.shape and rel(a, b) < TOL
+    assert out.shape == fx["output"].shape and rel(out, fx["output"]) < TOL
+    assert fx["hf_maxdiff"] < 1e-3
+    # DepthEmbedder wrapper: shape, range and the pixel-unshuffle order (vtdm/encoders.py:46-50)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((2, 3, 192, 256), generator=g) * 2 - 1
+    d = O.depth_embedder(sd, x, prefix=P)
+    assert d.shape == (2, 9, 24, 32) and float(d.min()) == 0.0 and float(d.max()) == 1.0
+    y = O.dpt_hybrid(sd, torch.nn.functional.interpolate(x, [64, 96], mode="bilinear"), P)[:, None]
+    y = torch.nn.functional.interpolate(y, [72, 96], mode="bilinear")
+    y = (y - y.amin(dim=(1, 2, 3), keepdim=True))
+    y = y / y.amax(dim=(1, 2, 3), keepdim=True)
+    assert torch.allclose(d[:, 4], y[:, 0, 1::3, 1::3], atol=1e-6)       # channel h0*3 + w0 = 4 <- offsets (1, 1)
