@@ -36,23 +36,26 @@ __global__ void silu_kernel(const float* __restrict__ x, unsigned short* __restr
     y[i] = f32_to_bf16(silu_f(x[i]));
 }
 
-// Activations of the CLIP vision towers of the conditioner, in place on bf16, 8 elements per thread:
-// kind 0 = exact-erf GELU (nn.GELU: OpenCLIP ViT-H/14), kind 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI ViT-L/14)
-__global__ void act_bf16_kernel(uint4* __restrict__ x, long n8, int kind) {
+// Elementwise activation on bf16, 8 elements per thread: out = act(x [+ y]); out may alias x.
+// kind 0 = exact-erf GELU (nn.GELU: OpenCLIP ViT-H/14, the ViT-B of MiDaS), 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI
+// ViT-L/14), 2 = ReLU (BiT bottlenecks and the fusion blocks of MiDaS DPT-hybrid), 3 = identity (a plain add)
+__global__ void add_act_bf16_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y, uint4* __restrict__ out, long n8, int kind) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-    uint4 v = x[i];
+    const uint4 v = x[i];
     unsigned int u[4] = {v.x, v.y, v.z, v.w};
+    unsigned int q[4] = {0u, 0u, 0u, 0u};
+    if (y) { const uint4 t = y[i]; q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float a = bf16_to_f32(u[j] & 0xffff), b = bf16_to_f32(u[j] >> 16);
+      float a = bf16_to_f32(u[j] & 0xffff) + bf16_to_f32(q[j] & 0xffff), b = bf16_to_f32(u[j] >> 16) + bf16_to_f32(q[j] >> 16);
       if (kind == 0) { a = gelu_erf_f(a); b = gelu_erf_f(b); }
-      else {
+      else if (kind == 1) {
         a = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * a));
         b = b * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * b));
-      }
+      } else if (kind == 2) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
       u[j] = pack_bf16x2(a, b);
     }
-    x[i] = make_uint4(u[0], u[1], u[2], u[3]);
+    out[i] = make_uint4(u[0], u[1], u[2], u[3]);
   }
 }
 
@@ -315,14 +318,21 @@ extern "C" int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* s
   return HI3D_OK;
 }
 
-extern "C" int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream) {
-  if (!x) HI3D_FAIL(HI3D_EINVAL, "act: null pointer");
-  if (n <= 0 || (n % 8)) HI3D_FAIL(HI3D_ESHAPE, "act: n must be a positive multiple of 8");
-  if (kind != 0 && kind != 1) HI3D_FAIL(HI3D_EINVAL, "act: kind must be 0 (gelu) or 1 (quick_gelu)");
-  if ((uintptr_t)x & 15) HI3D_FAIL(HI3D_EALIGN, "act: x not 16-byte aligned");
-  hipLaunchKernelGGL(act_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)x, (long)(n / 8), kind);
+extern "C" int hi3d_add_act_bf16(const void* x, const void* y, void* out, int64_t n, int32_t kind, void* stream) {
+  if (!x || !out) HI3D_FAIL(HI3D_EINVAL, "add_act: null pointer");
+  if (n <= 0 || (n % 8)) HI3D_FAIL(HI3D_ESHAPE, "add_act: n must be a positive multiple of 8");
+  if (kind < 0 || kind > 3) HI3D_FAIL(HI3D_EINVAL, "add_act: kind must be 0 (gelu), 1 (quick_gelu), 2 (relu) or 3 (identity)");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15) HI3D_FAIL(HI3D_EALIGN, "add_act: pointer not 16-byte aligned");
+  hipLaunchKernelGGL(add_act_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (const uint4*)y, (uint4*)out, (long)(n / 8), kind);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
+}
+
+extern "C" int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream) {
+  if (!x) HI3D_FAIL(HI3D_EINVAL, "act: null pointer");
+  if (kind < 0 || kind > 2) HI3D_FAIL(HI3D_EINVAL, "act: kind must be 0 (gelu), 1 (quick_gelu) or 2 (relu)");
+  return hi3d_add_act_bf16(x, nullptr, x, n, kind, stream);
 }
 
 extern "C" int hi3d_l2_normalize_rows(float* x, int32_t R, int32_t C, void* stream) {

@@ -370,13 +370,86 @@ def softmax_rows(s, R, N, ldp, scale):
     return p
 
 
+_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2, "identity": 3}
+
+
 def act_(x, kind):
-    """In-place activation of a contiguous bf16 tensor: kind 'gelu' (exact erf) or 'quick_gelu' (x sigmoid(1.702 x))."""
+    """In-place activation of a contiguous bf16 tensor: 'gelu' (exact erf), 'quick_gelu' (x sigmoid(1.702 x)), 'relu'."""
     _chk_dev(x)
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         raise _l.Hi3dError("act_: contiguous bf16 tensor required")
-    _l.check(_lib.hi3d_act_bf16(_p(x), x.numel(), {"gelu": 0, "quick_gelu": 1}[kind], _stream()), "hi3d_act_bf16")
+    _l.check(_lib.hi3d_act_bf16(_p(x), x.numel(), _ACT[kind], _stream()), "hi3d_act_bf16")
     return x
+
+
+def add_act(x, y=None, kind="identity", out=None):
+    """out = act(x + y) on contiguous bf16 tensors of one shape (y optional; out may be x)."""
+    _chk_dev(x, y, out)
+    if out is None:
+        out = torch.empty_like(x)
+    for t in (x, y, out):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or t.numel() != x.numel()):
+            raise _l.Hi3dError("add_act: contiguous bf16 tensors of one size required")
+    _l.check(_lib.hi3d_add_act_bf16(_p(x), _p(y), _p(out), x.numel(), _ACT[kind], _stream()), "hi3d_add_act_bf16")
+    return out
+
+
+def dpt_stem_conv(x, w):
+    """x fp32 [N, H, W, 3] channels-last, w fp32 [7, 7, 3, 64] (standardised) -> bf16 [N, ceil(H/2), ceil(W/2), 64]."""
+    _chk_dev(x, w)
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or not x.is_contiguous() or not w.is_contiguous():
+        raise _l.Hi3dError("dpt_stem_conv: contiguous fp32 tensors required")
+    if x.dim() != 4 or x.shape[-1] != 3 or tuple(w.shape) != (7, 7, 3, 64):
+        raise _l.Hi3dError("dpt_stem_conv: x [N,H,W,3], w [7,7,3,64]")
+    N, H, W = x.shape[:3]
+    y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, 64), device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_dpt_stem_conv(_p(x), _p(w), _p(y), N, H, W, _stream()), "hi3d_dpt_stem_conv")
+    return y
+
+
+def pool2(x, mode):
+    """x bf16 [N, H, W, C] -> [N, ceil(H/2), ceil(W/2), C]; mode 'max3' (3x3 max, SAME) or 'pick' (pixel 2oy, 2ox)."""
+    _chk_dev(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.dim() != 4:
+        raise _l.Hi3dError("pool2: contiguous bf16 [N,H,W,C] required")
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), device=x.device, dtype=torch.bfloat16)
+    _l.check(_lib.hi3d_pool2_nhwc(_p(x), _p(y), N, H, W, C, {"max3": 0, "pick": 1}[mode], _stream()), "hi3d_pool2_nhwc")
+    return y
+
+
+def resize_bilinear(x, Ho, Wo, align_corners=False):
+    """F.interpolate(mode='bilinear') on a channels-last [N, Hi, Wi, C] tensor, bf16 (C % 8 == 0) or fp32."""
+    _chk_dev(x)
+    if x.dtype not in (torch.bfloat16, torch.float32) or not x.is_contiguous() or x.dim() != 4:
+        raise _l.Hi3dError("resize_bilinear: contiguous bf16 / fp32 [N,Hi,Wi,C] required")
+    N, Hi, Wi, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
+    _l.check(_lib.hi3d_resize_bilinear_nhwc(_p(x), _p(y), N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0,
+                                            1 if x.dtype == torch.float32 else 0, _stream()), "hi3d_resize_bilinear_nhwc")
+    return y
+
+
+def dpt_head_out(x, w, b):
+    """x bf16 [M, C], w fp32 [C], b float -> fp32 [M]: relu(b + w . relu(x[m]))."""
+    _chk_dev(x, w)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or w.dtype != torch.float32 or w.numel() != x.shape[-1]:
+        raise _l.Hi3dError("dpt_head_out: x bf16 [M,C] contiguous, w fp32 [C]")
+    M = x.numel() // x.shape[-1]
+    y = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_dpt_head_out(_p(x), _p(w), float(b), _p(y), M, x.shape[-1], _stream()), "hi3d_dpt_head_out")
+    return y
+
+
+def depth_normalize_unshuffle(d, s):
+    """d fp32 [B, Hs, Ws] -> fp32 [B, s*s, Hs/s, Ws/s]: per-image min-max normalisation, then pixel-unshuffle."""
+    _chk_dev(d)
+    if d.dtype != torch.float32 or not d.is_contiguous() or d.dim() != 3:
+        raise _l.Hi3dError("depth_normalize_unshuffle: contiguous fp32 [B,Hs,Ws] required")
+    B, Hs, Ws = d.shape
+    out = torch.empty((B, s * s, Hs // s, Ws // s), device=d.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_depth_normalize_unshuffle(_p(d), _p(out), B, Hs, Ws, s, _stream()), "hi3d_depth_normalize_unshuffle")
+    return out
 
 
 def l2_normalize_rows_(x):

@@ -41,6 +41,20 @@ def synth_state_dict(shapes: dict, seed: int = 1) -> dict:
     return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
 
 
+# Residual-branch tails of the depth network (BiT bottlenecks' last GroupNorm gain, the ViT blocks' output projections,
+# the fusion blocks' second convolutions).  With every tensor drawn at unit scale a 70-layer random network amplifies a
+# perturbation of its input by ~3x per stage (measured: 2 % noise into BiT stage 2 -> 16 % out), so a bf16 run cannot
+# be told from a wrong one; trained networks do not behave like that (timm even initialises those gains to zero).
+# The depth fixtures therefore damp these tensors -- the same rule for the reference run, the oracle and the HIP path.
+RESIDUAL_TAILS = (".norm3.weight", ".attn.proj.weight", ".attn.proj.bias", ".mlp.fc2.weight", ".mlp.fc2.bias",
+                  "resConfUnit1.conv2.weight", "resConfUnit1.conv2.bias", "resConfUnit2.conv2.weight", "resConfUnit2.conv2.bias")
+
+
+def damp_residual_tails(sd: dict, factor: float) -> dict:
+    """{key: tensor} with the residual-branch tails (RESIDUAL_TAILS) multiplied by `factor`."""
+    return {k: (v * factor if k.endswith(RESIDUAL_TAILS) else v) for k, v in sd.items()}
+
+
 def fill_module_on_device_(module: torch.nn.Module, seed: int = 1, prefix: str = "") -> None:
     """Benchmark-only variant: same per-key distributions as `synth_tensor`, drawn with the
     DEVICE generator directly into the parameters (no 6 GB host round trip per rank).  Values

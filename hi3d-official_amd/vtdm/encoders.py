@@ -1,9 +1,9 @@
 """vtdm.encoders mirror (reference: vtdm/encoders.py): the conditioner embedders Hi3D adds to sgm.
 
-Built: `AesEmbedder` (:56-91) -- OpenAI CLIP ViT-L/14 image features of the clip's middle frame on the gfx950 ViT
+`AesEmbedder` (:56-91) -- OpenAI CLIP ViT-L/14 image features of the clip's middle frame on the gfx950 ViT
 runtime, L2-normalised, through the 5-layer aesthetic MLP (tools/aes_score.py:14-33), concatenated with a 255-wide
-sinusoidal embedding of 100 x score.  Not built: `DepthEmbedder` (:15-53, MiDaS DPT-hybrid: a ResNet-50 + ViT-B hybrid
-backbone with a DPT decoder, `annotator/midas` + timm; once per clip, v02 only) -- it raises by name.
+sinusoidal embedding of 100 x score.  `DepthEmbedder` (:15-53) -- MiDaS DPT-hybrid (a BiT ResNet-50 + ViT-B hybrid
+backbone with a DPT decoder: `annotator/midas` + timm in the reference) on hi3d_hip/runtime_dpt.py; once per clip.
 """
 import torch
 import torch.nn as nn
@@ -81,10 +81,65 @@ class AesEmbedder(AbstractEmbModel):
         return torch.cat([h, emb], dim=1)
 
 
-class DepthEmbedder(AbstractEmbModel):
-    def __init__(self, *a, **k):
+class _MidasInference(nn.Module):
+    """`MiDaSInference` (annotator/midas/api.py:145-165): `.model` is the DPTDepthModel -- here its parameters under the
+    reference's names (`model.pretrained.model.*`, `model.pretrained.act_postprocess*`, `model.scratch.*`) and the packed
+    gfx950 runtime, rebuilt when a parameter changes."""
+
+    def __init__(self):
         super().__init__()
-        raise NotImplementedError(
-            "vtdm.encoders.DepthEmbedder (MiDaS DPT-hybrid depth, v02 conditioner, once per clip) is not part of the "
-            "MI355X hot-path framework: feed a precomputed depth `concat` (9 x h x w per frame, 3 x 3 pixel-unshuffled, "
-            "min-max normalised: vtdm/encoders.py:36-50) or run the reference embedder once per clip")
+        from hi3d_hip.runtime_dpt import dpt_hybrid_shapes
+        self.model = ParamTree(dpt_hybrid_shapes())
+        self._rt = None
+
+    def runtime(self, device):
+        from hi3d_hip.runtime_dpt import DPTHybridRuntime
+        from sgm.util import params_key
+        key = params_key(self, device)
+        if self._rt is None or self._rt[0] != key:
+            self._rt = (key, DPTHybridRuntime(self.state_dict(), "model.", device))
+        return self._rt[1]
+
+
+class DepthEmbedder(AbstractEmbModel):
+    """vtdm/encoders.py:15-53: MiDaS DPT-hybrid inverse depth of every conditioning frame at 1 / 2.6666 of its size,
+    resampled to 3/8 of the frame, min-max normalised per frame and 3 x 3 pixel-unshuffled: [(b t), 9, H/8, W/8] (the
+    `concat` conditioning of stage 2), or [b, 9, t, H/8, W/8] with `use_3d`.  The reference loads
+    "ckpts/dpt_hybrid_384.pt" in its constructor; here the parameters are a ParamTree under the same names
+    (`model.model.*`): `init_from_midas_ckpt(path)` or the Hi3D checkpoint's `conditioner.embedders.*` entries fill them."""
+
+    def __init__(self, freeze=True, use_3d=False, shuffle_size=3, scale_factor=2.6666):
+        super().__init__()
+        self.model = _MidasInference()
+        self.use_3d, self.shuffle_size, self.scale_factor = use_3d, shuffle_size, scale_factor
+        if freeze:
+            self.freeze()
+
+    def freeze(self):
+        self.model = self.model.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def init_from_midas_ckpt(self, path):
+        """dpt_hybrid_384.pt / dpt_hybrid-midas-501f0c75.pt: a DPTDepthModel state_dict (optionally under 'model')."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = sd.get("model", sd) if isinstance(sd, dict) and "model" in sd and not torch.is_tensor(sd["model"]) else sd
+        missing, unexpected = self.model.model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+        if missing:
+            raise KeyError(f"MiDaS checkpoint lacks {len(missing)} keys, e.g. {missing[:3]}")
+
+    @torch.no_grad()
+    def forward(self, x):
+        T = 16                                                   # (hard-wired in the reference: vtdm/encoders.py:34)
+        if x.dim() == 4:
+            if x.shape[0] % T:
+                raise ValueError(f"DepthEmbedder: {x.shape[0]} frames are not a multiple of t = {T}")
+            y = x
+        else:
+            B, C, T, H, W = x.shape
+            y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+        dev = y.device if y.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        out = self.model.runtime(dev).depth_embed(y, self.shuffle_size, self.scale_factor)
+        if self.use_3d:
+            out = out.reshape(-1, T, *out.shape[1:]).permute(0, 2, 1, 3, 4)
+        return out

@@ -217,7 +217,41 @@ int hi3d_silu_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 /* In-place activation on n bf16 elements (n % 8 == 0) -- the MLP of the conditioner's CLIP vision towers:
  * kind 0: exact-erf GELU (open_clip ViT-H/14 `nn.GELU`, sgm/modules/encoders/modules.py:592-596 builds the tower),
  * kind 1: QuickGELU x * sigmoid(1.702 x) (OpenAI CLIP ViT-L/14 of vtdm/encoders.py:59).                   */
-int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream);
+int hi3d_act_bf16(void* x, int64_t n, int32_t kind, void* stream);        /* also kind 2: ReLU */
+
+/* out = act(x + y) on n bf16 elements (n % 8 == 0; y may be NULL; out may alias x); kind as above plus 3 = identity.
+ * The ReLUs and residual adds of MiDaS DPT-hybrid that sit behind a GroupNorm and so cannot ride a GEMM epilogue:
+ * the BiT bottleneck's `act3(x + shortcut)` (timm resnetv2.Bottleneck, built by annotator/midas/vit.py:499), the
+ * pre-activation of ResidualConvUnit_custom and the skip add of FeatureFusionBlock_custom
+ * (annotator/midas/blocks.py:310-323, 376-379).                                                             */
+int hi3d_add_act_bf16(const void* x, const void* y, void* out, int64_t n, int32_t kind, void* stream);
+
+/* ---- depth conditioner (stage 2 / v02): vtdm/encoders.py:15-53 DepthEmbedder = MiDaS DPT-hybrid
+ * (annotator/midas/dpt_depth.py:60-106) + min-max normalisation + 3x3 pixel-unshuffle.  The GEMM-shaped layers run
+ * on hi3d_gemm / hi3d_attention_* / hi3d_groupnorm_silu / hi3d_layernorm; these are the remaining pieces.
+ *
+ * BiT stem convolution: timm StdConv2dSame(3, 64, kernel 7, stride 2), TensorFlow 'SAME' padding.
+ * x fp32 [N][H][W][3], w fp32 [7][7][3][64] (already weight-standardised), y bf16 [N][ceil(H/2)][ceil(W/2)][64]. */
+int hi3d_dpt_stem_conv(const float* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, void* stream);
+
+/* Stride-2 window over channels-last bf16 [N][H][W][C] (C % 8 == 0) -> [N][ceil(H/2)][ceil(W/2)][C].
+ * mode 0: 3x3 max with 'SAME' padding (timm MaxPool2dSame of the BiT stem);
+ * mode 1: pixel (2 oy, 2 ox) -- the gather of a 1x1 stride-2 convolution (BiT DownsampleConv shortcuts).   */
+int hi3d_pool2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t mode, void* stream);
+
+/* torch.nn.functional.interpolate(mode="bilinear", align_corners=...) on channels-last [N][Hi][Wi][C] ->
+ * [N][Ho][Wo][C]; bf16 (C % 8 == 0) or fp32 (any C).  DepthEmbedder's input / output resizes
+ * (vtdm/encoders.py:41,46), the x2 of FeatureFusionBlock_custom (blocks.py:383-386) and of the head
+ * (dpt_depth.py:96).                                                                                        */
+int hi3d_resize_bilinear_nhwc(const void* x, void* y, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                              int32_t C, int32_t align_corners, int32_t is_f32, void* stream);
+
+/* The head's tail (dpt_depth.py:97-100): y[m] = relu(b + sum_c w[c] * relu(x[m][c])); x bf16 [M][C], y fp32 [M]. */
+int hi3d_dpt_head_out(const void* x, const float* w, float b, float* y, int64_t M, int32_t C, void* stream);
+
+/* vtdm/encoders.py:47-50: per image y = (d - min) / max(max(d - min), 1e-6), then
+ * 'b 1 (h h0) (w w0) -> b (h0 w0) h w' with h0 = w0 = s.  d fp32 [B][Hs][Ws] -> out fp32 [B][s*s][Hs/s][Ws/s]. */
+int hi3d_depth_normalize_unshuffle(const float* d, float* out, int32_t B, int32_t Hs, int32_t Ws, int32_t s, void* stream);
 
 /* x[r] /= ||x[r]||_2 in place, fp32 [R][C]; zero rows stay zero (tools/aes_score.py:56-61 `normalized`,
  * applied to the CLIP image features before the aesthetic MLP, vtdm/encoders.py:88-89)                   */

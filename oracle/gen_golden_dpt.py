@@ -26,6 +26,7 @@ import synth  # noqa: E402
 import timm_standin  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+DAMP = 0.25
 PREFIX = "model.model."          # DepthEmbedder.model (MiDaSInference) .model (DPTDepthModel): vtdm/encoders.py:18, api.py:159
 
 
@@ -36,6 +37,7 @@ def build_reference(seed):
     from annotator.midas.dpt_depth import DPTDepthModel
     m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
     synth.fill_module_(m, seed, prefix=PREFIX)
+    m.load_state_dict(synth.damp_residual_tails(m.state_dict(), DAMP))      # (see hi3d_hip.synth.RESIDUAL_TAILS)
     return m
 
 
@@ -104,7 +106,7 @@ def check_hf(ref_model, x, want):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-hf", action="store_true")
-    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=5)      # (a seed whose depth map is mostly positive: 12 % of the pixels at the final ReLU's zero)
     a = ap.parse_args()
     if a.check_hf:                     # (before the timm stand-in enters sys.modules: transformers probes for a real timm)
         from transformers import DPTConfig, DPTForDepthEstimation  # noqa: F401
@@ -116,7 +118,7 @@ def main():
     with torch.no_grad():
         out = m(x)
         layers = rvit.forward_vit(m.pretrained, x)
-    fx = dict(kind="dpt_hybrid", weight_seed=a.seed, key_prefix=PREFIX, x=x, output=out,
+    fx = dict(kind="dpt_hybrid", weight_seed=a.seed, damp=DAMP, key_prefix=PREFIX, x=x, output=out,
               layers=[t.clone() for t in layers], shapes={k: tuple(v.shape) for k, v in m.state_dict().items()})
     print(f"dpt_hybrid: out {tuple(out.shape)} absmax {out.abs().max():.4f} mean {out.mean():.4f} zeros {(out == 0).float().mean():.3f} "
           f"({time.time() - t0:.1f}s)")

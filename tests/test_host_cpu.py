@@ -332,3 +332,26 @@ def test_init_from_ckpt_three_formats(tmp_path, fmt):
 def params_key_of(m):
     from sgm.util import params_key
     return params_key(m.model.diffusion_model, "cpu")
+
+
+def test_depth_embedder_mirror_names_match_reference():
+    """vtdm.encoders.DepthEmbedder owns exactly the parameters of the reference's DPTDepthModel (as recorded from the
+    reference's own MiDaS code by oracle/gen_golden_dpt.py) under `model.model.*` (MiDaSInference.model), and the v02
+    inference YAML now instantiates it instead of the unavailable placeholder."""
+    import yaml
+    from hi3d_hip.runtime_dpt import dpt_hybrid_shapes
+    from sgm.modules.encoders.modules import _Unavailable
+    from sgm.util import instantiate_from_config
+    from vtdm.encoders import DepthEmbedder
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "dpt_hybrid_64x96.pt"), weights_only=False)
+    assert dpt_hybrid_shapes() == fx["shapes"]
+    e = DepthEmbedder()
+    sd = e.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {fx["key_prefix"] + k: s for k, s in fx["shapes"].items()}
+    assert all(not p.requires_grad for p in e.parameters())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    y = yaml.safe_load(open(os.path.join(root, "hi3d-official_amd", "configs", "inference-v02.yaml")))
+    cfgs = [c for c in y["model"]["params"]["conditioner_config"]["params"]["emb_models"] if c["target"].endswith("DepthEmbedder")]
+    assert len(cfgs) == 1
+    emb = instantiate_from_config(cfgs[0])
+    assert isinstance(emb, DepthEmbedder) and not isinstance(emb, _Unavailable) and emb.shuffle_size == 3

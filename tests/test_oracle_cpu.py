@@ -140,7 +140,7 @@ def test_dpt_hybrid_oracle_matches_reference_midas():
     that run on the same weights (pins the stand-in backbone: must be fp32 noise)."""
     fx = load("dpt_hybrid_64x96")
     P = fx["key_prefix"]
-    sd = synth.synth_state_dict({P + k: s for k, s in fx["shapes"].items()}, fx["weight_seed"])
+    sd = synth.damp_residual_tails(synth.synth_state_dict({P + k: s for k, s in fx["shapes"].items()}, fx["weight_seed"]), fx["damp"])
     out, layers = O.dpt_hybrid(sd, fx["x"], P, return_layers=True)
     for a, b in zip(layers, fx["layers"]):
         assert a.shape == b.shape and rel(a, b) < TOL
