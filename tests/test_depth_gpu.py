@@ -145,3 +145,42 @@ def test_depth_embedder_matches_oracle(dev):
     assert out3.shape == (1, 9, 16, 32, 40) and torch.equal(out3[0].permute(1, 0, 2, 3), out)
     with pytest.raises(ValueError):
         emb(x[:5].to(dev))
+
+
+def test_v02_conditioner_end_to_end(dev):
+    """The stage-2 conditioner exactly as pipeline_i2v_eval_v02.py:104-113 drives it: VideoLDM.add_custom_cond builds the
+    batch from the clip, GeneralConditioner (instantiated from configs/inference-v02.yaml; CLIP tower reduced) turns it
+    into c / uc with force_uc_zero_embeddings -- crossattn [1,1,1024] (CLIP image token), vector [1,512] (elevation ||
+    cond_aug embeddings), concat [16, 9 + 4, h, w] (depth unshuffle || conditioning-frame latents); no embedder is a
+    placeholder any more.  The depth channels are checked against the oracle on the batch's own (noised) frames."""
+    import yaml
+    import hi3d_oracle as O
+    from conftest import shrink_conditioner
+    from hi3d_hip import synth
+    from sgm.modules.encoders.modules import _Unavailable
+    from sgm.util import instantiate_from_config
+    from vtdm.vtdm_gen_stage2_degradeImage import VideoLDM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    y = shrink_conditioner(yaml.safe_load(open(os.path.join(root, "hi3d-official_amd", "configs", "inference-v02.yaml"))))
+    cond = instantiate_from_config(y["model"]["params"]["conditioner_config"])
+    assert not any(isinstance(e, _Unavailable) for e in cond.embedders)
+    synth.fill_module_(cond, seed=3)
+    depth = [e for e in cond.embedders if type(e).__name__ == "DepthEmbedder"][0]
+    dsd = synth.damp_residual_tails({k: v.clone().float() for k, v in depth.state_dict().items()}, 0.25)
+    depth.load_state_dict(dsd)
+    cond = cond.to(dev)
+    T, H, W = 16, 256, 256
+    video = (torch.rand((1, 3, T, H, W), generator=torch.Generator().manual_seed(12)) * 2 - 1).to(dev)
+    stub = type("M", (), {"num_samples": T})()
+    batch = VideoLDM.add_custom_cond(stub, {"video": video, "elevation": torch.tensor([10], device=dev)}, infer=True)
+    c, uc = cond.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames", "cond_frames_without_noise"])
+    assert c["crossattn"].shape == (1, 1, 1024) and c["vector"].shape == (1, 512)
+    assert c["concat"].shape == (T, 13, H // 8, W // 8) == uc["concat"].shape
+    assert float(uc["concat"].abs().max()) == 0.0 and float(uc["crossattn"].abs().max()) == 0.0
+    assert torch.equal(uc["vector"], c["vector"])
+    ref = O.depth_embedder(dsd, batch["cond_frames"].float().cpu(), prefix="model.model.")
+    got = c["concat"][:, :9].float().cpu()
+    print(f"v02 concat depth channels: max |diff| {(got - ref).abs().max():.4f} cos {cos(got, ref):.6f}")
+    # (other weights than the fixture's, and the min-max normalisation divides the error by this clip's depth range)
+    assert (got - ref).abs().max() < 1e-1 and (got - ref).abs().mean() < 1e-2 and cos(got, ref) > 0.999
+    assert torch.isfinite(c["concat"]).all() and float(c["concat"][:, 9:].abs().max()) > 0
