@@ -184,3 +184,33 @@ def test_v02_conditioner_end_to_end(dev):
     # (other weights than the fixture's, and the min-max normalisation divides the error by this clip's depth range)
     assert (got - ref).abs().max() < 1e-1 and (got - ref).abs().mean() < 1e-2 and cos(got, ref) > 0.999
     assert torch.isfinite(c["concat"]).all() and float(c["concat"][:, 9:].abs().max()) > 0
+
+
+def test_depth_embedder_at_size(dev):
+    """The shipped shape: 16 conditioning frames of 1024 x 1024 -> MiDaS at 384 x 384 (int(1024 / 2.6666 / 32) * 32) ->
+    [16, 9, 128, 128].  The CPU oracle needs minutes at this size, so the checks are properties: range and per-frame
+    min / max of the normalisation, frame independence (a frame's result does not depend on its batch neighbours: bitwise),
+    and agreement with the same frames run as a smaller batch."""
+    import time
+    from hi3d_hip import synth
+    from vtdm.encoders import DepthEmbedder
+    _, P, sd = _golden()
+    emb = DepthEmbedder()
+    emb.load_state_dict(sd)
+    g = torch.Generator().manual_seed(31)
+    base = F.interpolate(torch.rand((4, 3, 32, 32), generator=g), (1024, 1024), mode="bilinear") * 2 - 1   # smooth images
+    x = base[[0, 1, 2, 3, 0, 1, 2, 3, 3, 2, 1, 0, 0, 0, 1, 1]].to(dev)
+    out = emb(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = emb(x)
+    torch.cuda.synchronize()
+    print(f"DepthEmbedder 16 x 1024^2: {(time.time() - t0) * 1e3:.1f} ms")
+    assert out.shape == (16, 9, 128, 128) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert float(out.min()) == 0.0 and float(out.max()) == 1.0
+    assert all(float(out[i].min()) == 0.0 and float(out[i].max()) == 1.0 for i in range(16))
+    for i, j in ((0, 4), (0, 11), (0, 12), (1, 5), (1, 15), (2, 9), (3, 8)):
+        assert torch.equal(out[i], out[j])
+    rt = emb.model.runtime(dev)
+    four = rt.depth_embed(x[:4])              # (another batch size picks other GEMM tiles: same values to rounding, not bitwise)
+    assert (four - out[:4]).abs().max() < 3e-2 and cos(four, out[:4]) > 0.9995
