@@ -32,6 +32,12 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTI
   python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.csv 2>&1
   rm -rf /tmp/pmc_sq$i
 done
+if [ -n "$LIGHT" ]; then     # (the per-shape conv traffic and the GEMM variant sweep only change when gemm.hip does)
+  cat $O/s2_bench.json | cut -c1-900; cat $O/s1_bench.json | cut -c1-300; cat $O/vae_bench.json | cut -c1-400
+  cat $O/s2_fp8qk_bench.json | cut -c1-300; head -14 $O/s2_kernel_stats.csv; head -8 $O/s2_pmc_FETCH_SIZE.csv
+  head -8 $O/s2_pmc_WRITE_SIZE.csv; head -14 $O/s2_pmc_sq1.csv; head -8 $O/s2_pmc_sq2.csv
+  exit 0
+fi
 # conv3x3 traffic per shape: FETCH_SIZE counts Infinity-Cache hits too, so the weights -- re-streamed
 # from the 256 MB cache once per wave of m-tiles when K*N*2 exceeds the 4 MB L2 -- show up in it; the three levels separate
 # the input halo (small weights, 128^2) from the weight stream (29.5 MB of weights, 32^2)
