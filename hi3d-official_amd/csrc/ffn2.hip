@@ -53,6 +53,8 @@ constexpr int HGB = GBM * 128;             // hg: 128 rows x 64 hidden
 constexpr int B1B = 8 * GC * 4;            // the packed first-layer bias, fp32 (read in every GELU slice: no VMEM loads inside the loop)
 constexpr int X9B = GBM * 64;              // the last 32 channels of the X tile (k = 288..319): the 80 registers of a whole X tile, the
                                            // output tile (80) and the rest do not fit in 256 -- 9 of the 10 half K steps stay in registers
+constexpr int G1D = 2;                     // first GEMM: fragment pairs in flight (of the 5 per phase; 3 / 5 below measured the same, more registers)
+constexpr int G2D = 3;                     // second GEMM: W2 fragments in flight (of the 10 per phase)
 constexpr int FFN2_LDS = 2 * W1S + 2 * W2H + HGB + B1B + X9B;      // 157,696 B
 
 __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Params p) {
@@ -158,9 +160,9 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(s + nt * 512);
   };
-  auto g1_read = [&](bf16x8 (&wf)[2][2], int stage, int half) {
+  auto g1_read = [&](bf16x8 (&wf)[G1D][2], int stage, int half) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) g1_frag(wf[q], stage, half * 5 + q);
+    for (int q = 0; q < G1D; ++q) g1_frag(wf[q], stage, half * 5 + q);
   };
   auto g1_step = [&](const bf16x8 (&f)[2], f32x4 (&acc)[2][2], int kk, const bf16x8 (&x9)[2], const f32x4 (&bias)[2]) {
 #pragma unroll
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[nt], kk < 9 ? xr[kk < 9 ? kk : 0][mt] : x9[mt],
                                                                 kk == 0 ? bias[nt] : acc[mt][nt], 0, 0, 0);
   };
-  auto g1_mfma = [&](bf16x8 (&wf)[2][2], f32x4 (&acc)[2][2], int stage, int half, const f32x4 (&bias)[2]) {
+  auto g1_mfma = [&](bf16x8 (&wf)[G1D][2], f32x4 (&acc)[2][2], int stage, int half, const f32x4 (&bias)[2]) {
     const int k0 = half * 5;
     bf16x8 x9[2];
     if (half == 1) {                               // the X fragments of the last half K step (requested three steps ahead of their use)
@@ -179,10 +181,10 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      g1_step(wf[q & 1], acc, k0 + q, x9, bias);
-      if (q + 2 < 5) {                             // this pair's registers take the pair two steps ahead
+      g1_step(wf[q % G1D], acc, k0 + q, x9, bias);
+      if (q + G1D < 5) {                           // this pair's registers take the pair G1D steps ahead
         __builtin_amdgcn_sched_barrier(0);
-        g1_frag(wf[q & 1], stage, k0 + q + 2);
+        g1_frag(wf[q % G1D], stage, k0 + q + G1D);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -191,20 +193,20 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // second GEMM, one phase: K half `kh` (32 hidden columns) of the chunk whose hg half is ready.  The ten W2 fragments
   // do not fit beside X and the output tile: three are read in the load segment, the others into the registers of the
   // fragment just issued, three column blocks (6 MFMAs) ahead of their use.
-  auto g2_read = [&](bf16x8 (&xf)[2], bf16x8 (&wf)[3], int kh) {
+  auto g2_read = [&](bf16x8 (&xf)[2], bf16x8 (&wf)[G2D], int kh) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) xf[mt] = *(const bf16x8*)(sHG + hg_off + mt * 2048 + (((kh * 4 + fg) ^ f_sw) << 4));
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) wf[nt] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + nt * 256);
+    for (int nt = 0; nt < G2D; ++nt) wf[nt] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + nt * 256);
   };
-  auto g2_mfma = [&](const bf16x8 (&xf)[2], bf16x8 (&wf)[3], int kh) {
+  auto g2_mfma = [&](const bf16x8 (&xf)[2], bf16x8 (&wf)[G2D], int kh) {
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt % 3], xf[mt], acc2[mt][nt], 0, 0, 0);
-      if (nt + 3 < 10) {                           // this fragment's registers take the one three column blocks ahead
+      for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt % G2D], xf[mt], acc2[mt][nt], 0, 0, 0);
+      if (nt + G2D < 10) {                         // this fragment's registers take the one G2D column blocks ahead
         __builtin_amdgcn_sched_barrier(0);
-        wf[nt % 3] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + (nt + 3) * 256);
+        wf[nt % G2D] = *(const bf16x8*)(sW2 + kh * W2H + w2_off + (nt + G2D) * 256);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -232,11 +234,11 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // One loop iteration = one HALF chunk hc (32 hidden columns = 64 packed W1 rows; slot s = hc & 1 of every ring).
   // Compute segments hold MFMAs and their rolling fragment reads only; everything else sits in the load segments, under
   // the other group's MFMAs:
-  //     Ph1  load: GELU(hc-1) rows 16-31 -> hg half s^1; bias, fragments
+  //     Ph1  load: bias, fragments
   //          compute: W1(hc) k 0-159 x X -> acc1 (from the bias)
   //     Ph2  load: wait W2(hc-1); request W1(hc+1) -> W1 slot s^1; fragments
   //          compute: W1(hc) k 160-319 x X -> acc1
-  //     Ph3  load: wait W1(hc+1); request W2(hc) -> W2 slot s; GELU(hc) rows 0-15 -> hg half s; fragments of hg half s^1 / W2(hc-1)
+  //     Ph3  load: wait W1(hc+1); request W2(hc) -> W2 slot s; GELU(hc) -> hg half s; fragments of hg half s^1 / W2(hc-1)
   //          compute: hg half s^1 x W2(hc-1) -> acc2 (the previous half chunk)
   // Ring protocol.  A phase reads LDS in its load segment AND (the rolling fragments) in its compute segment, and the
   // late group runs one barrier behind: the last read of phase k happens in the slot in which the early group already
@@ -250,21 +252,20 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     const int sl = hc & 1;
     // ---- Ph1
     {
-      bf16x8 wf[2][2];
+      bf16x8 wf[G1D][2];
       f32x4 bias[2];
       if (cur) {
         g1_read(wf, sl, 0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) bias[nt] = *(const f32x4*)(b1p + hc * 64 + nt * 4);
       }
-      if (prev) gelu_store(acc1, sl ^ 1, 1);
       seg_end();
       if (cur) g1_mfma(wf, acc1, sl, 0, bias);
       cseg_end();
     }
     if (cur) {
       // ---- Ph2
-      bf16x8 wf[2][2];
+      bf16x8 wf[G1D][2];
       f32x4 bias[2];                               // (unused: k > 0)
       // W2(hc-1) (requested in the previous Ph3, read in this Ph3) has landed: nothing younger is in flight
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     }
     // ---- Ph3
     {
-      bf16x8 xf[2], wf[3];
+      bf16x8 xf[2], wf[G2D];
       if (prev) g2_read(xf, wf, sl ^ 1);
       if (cur) {
         // W1(hc+1) (requested in Ph2, read from the next Ph1 on) has landed: nothing younger is in flight.  The last
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue_w2(hc, sl);
         if (hc + 1 == NHC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        gelu_store(acc1, sl, 0);
+        gelu_store(acc1, sl, 0);                   // (both row halves here: four independent dependency chains instead of two --
+        gelu_store(acc1, sl, 1);                   //  the GELU is latency-bound, ~11 cycles per instruction with two)
       }
       seg_end();
       if (prev) g2_mfma(xf, wf, sl ^ 1);
