@@ -21,6 +21,7 @@
 //     layout directly; VALU kernel on v_dot2c_f32_bf16 (0.05 % of the step FLOPs, its
 //     cost is the q/k/v/o traffic).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -32,6 +33,7 @@ __device__ __forceinline__ int swap_bits23(int i) {
 struct AttnParams {
   const char* q; const char* k; const char* vt; unsigned short* out;
   int B, H, Sq, Skv, ldq, ldk, ldvt, ldo, nqt;
+  int force_exact;    // debug (HI3D_ATTN_FORCE_EXACT=1): every key tile runs the exact pre-pass
   float scale_log2;   // softmax scale * log2(e)
 };
 
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 
     bf16x8 pf[QB][4];
     float psum[QB];
-    bool exact = (j == 0) || ragged;
+    bool exact = (j == 0) || ragged || p.force_exact;
     for (;;) {
       if (exact) {
         // exact pre-pass: move the rows' reference point to the true maximum seen so far
@@ -460,6 +462,7 @@ extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void*
   p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)vt; p.out = (unsigned short*)out;
   p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_vt; p.ldo = ldo;
   p.nqt = (S_q + Q_TILE - 1) / Q_TILE;
+  { const char* e = getenv("HI3D_ATTN_FORCE_EXACT"); p.force_exact = (e && atoi(e)) ? 1 : 0; }
   p.scale_log2 = scale * 1.4426950408889634f;
   const long nblk = (long)p.nqt * H * B;
   if (nblk > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: grid too large");
