@@ -103,6 +103,41 @@ def check_hf(ref_model, x, want):
     return d
 
 
+def reference_depth_embedder(dpt):
+    """The reference's own vtdm.encoders.DepthEmbedder / annotator.midas.api.MiDaSInference classes around `dpt`.
+    Their modules import packages that are absent here and unused by forward(): cv2 and torchvision (MiDaS's numpy
+    image transforms), clip, raft, softsplat (other embedders of the same file) -- inert stand-ins; the constructors
+    (which read ckpts/dpt_hybrid_384.pt and call .cuda()) are bypassed, forward() is the reference's."""
+    import types
+    import ref_import
+    ref_import.install()
+
+    def stub(name, **attrs):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            m.__path__ = []
+            sys.modules[name] = m
+        return sys.modules[name]
+    stub("cv2", INTER_CUBIC=2, INTER_AREA=3)
+    stub("torchvision")
+    stub("torchvision.transforms", Compose=lambda ts: ts)
+    stub("torchvision.models")
+    stub("torchvision.models.optical_flow", raft_large=None)
+    stub("clip")
+    stub("tools.softmax_splatting")
+    stub("tools.softmax_splatting.softsplat", softsplat=None)
+    from annotator.midas.api import MiDaSInference
+    from vtdm.encoders import DepthEmbedder
+    inf = MiDaSInference.__new__(MiDaSInference)
+    torch.nn.Module.__init__(inf)
+    inf.model = dpt
+    emb = DepthEmbedder.__new__(DepthEmbedder)
+    torch.nn.Module.__init__(emb)
+    emb.model, emb.use_3d, emb.shuffle_size, emb.scale_factor = inf, False, 3, 2.6666
+    return emb.eval()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-hf", action="store_true")
@@ -126,6 +161,14 @@ def main():
         xs = torch.rand((1, 3, 64, 64), generator=g) * 2 - 1
         with torch.no_grad():
             fx["hf_maxdiff"] = check_hf(m, xs, m(xs))
+    # DepthEmbedder.forward itself (resizes, min-max, unshuffle) through the reference class: 16 frames (t = 16 is
+    # hard-wired there) of 96 x 128 -> MiDaS at 32 x 32 -> [16, 9, 12, 16]; the input is re-drawn from its seed by the tests
+    emb = reference_depth_embedder(m)
+    xe = torch.rand((16, 3, 96, 128), generator=torch.Generator().manual_seed(77)) * 2 - 1
+    with torch.no_grad():
+        ye = emb(xe.clone())
+    fx["embedder_input_seed"], fx["embedder_input_shape"], fx["embedder_output"] = 77, tuple(xe.shape), ye
+    print(f"DepthEmbedder (reference class): out {tuple(ye.shape)} min {ye.min():.3f} max {ye.max():.3f}")
     torch.save(fx, os.path.join(GOLD, "dpt_hybrid_64x96.pt"))
 
 

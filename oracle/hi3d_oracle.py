@@ -479,7 +479,8 @@ def aes_embedder(sd, video, heads=16, clip_prefix="aesthetic_model.visual.", mlp
 # --------------------------------------------------------------------------------------
 # PARITY PIN: the DPT side (hooks, readout projection, reassemble, fusion, head) restates the reference's vendored
 # annotator/midas/{vit,blocks,dpt_depth}.py and is pinned against THAT code (tests/golden/dpt_hybrid_64x96.pt,
-# oracle/gen_golden_dpt.py).  The backbone is timm's `vit_base_resnet50_384` (annotator/midas/vit.py:499; timm is a
+# oracle/gen_golden_dpt.py); depth_embedder() is pinned against the reference's own vtdm.encoders.DepthEmbedder.forward
+# (same fixture: the class run with its constructor bypassed, bit-exact).  The backbone is timm's `vit_base_resnet50_384` (annotator/midas/vit.py:499; timm is a
 # pip dependency, absent from /root/reference and from this container): restated from the published BiT-ResNetV2 /
 # ViT architecture, and pinned against HuggingFace's independent DPTForDepthEstimation(is_hybrid=True) with its own
 # BiT backbone (8.8e-5 on shared weights, gen_golden_dpt.py --check-hf) -- "parity unpinned" against timm proper.

@@ -146,7 +146,12 @@ def test_dpt_hybrid_oracle_matches_reference_midas():
         assert a.shape == b.shape and rel(a, b) < TOL
     assert out.shape == fx["output"].shape and rel(out, fx["output"]) < TOL
     assert fx["hf_maxdiff"] < 1e-3
-    # DepthEmbedder wrapper: shape, range and the pixel-unshuffle order (vtdm/encoders.py:46-50)
+    # DepthEmbedder.forward vs the reference's own class (vtdm/encoders.py:31-53 run by oracle/gen_golden_dpt.py with
+    # MiDaSInference around the same network): resizes, per-frame min-max, 3x3 pixel-unshuffle
+    xe = torch.rand(fx["embedder_input_shape"], generator=torch.Generator().manual_seed(fx["embedder_input_seed"])) * 2 - 1
+    de = O.depth_embedder(sd, xe, prefix=P)
+    assert de.shape == fx["embedder_output"].shape and (de - fx["embedder_output"]).abs().max() < 1e-5
+    # ... and its shape, range and unshuffle order spelled out
     g = torch.Generator().manual_seed(5)
     x = torch.rand((2, 3, 192, 256), generator=g) * 2 - 1
     d = O.depth_embedder(sd, x, prefix=P)
