@@ -183,7 +183,7 @@ def test_ffn_geglu_fused(dev, M, blend):
 @pytest.mark.parametrize("blend", [False, True])
 def test_ffn_geglu_race_screen(dev, blend, monkeypatch):
     """The fused feed-forward keeps weight rings, an hg slab and two staggered wave groups in step with counted waits
-    and raw barriers only: many blocks per CU, twelve launches -- the outputs must be bitwise repeatable (a ring read
+    and raw barriers only: many blocks per CU, thirty launches -- the outputs must be bitwise repeatable (a ring read
     before its data landed, or overwritten too early, shows up as run-to-run differences), and the two forms of the
     kernel (HI3D_FFN_V=1: the lock-step first form) must agree to rounding."""
     from hi3d_hip import ops
@@ -199,7 +199,7 @@ def test_ffn_geglu_race_screen(dev, blend, monkeypatch):
     w1p, b1p, w2p, b2 = w1p.to(dev), b1p.to(dev), pack_linear(w2).to(dev), b2.to(dev)
     run = lambda: ops.ffn_geglu(x, w1p, b1p, w2p, b2, M=M, C=C, R1=R1, **kw)
     first = run()
-    for _ in range(11):
+    for _ in range(29):
         assert torch.equal(run(), first)
     monkeypatch.setenv("HI3D_FFN_V", "1")
     other = run()
