@@ -39,7 +39,7 @@ __global__ void silu_kernel(const float* __restrict__ x, unsigned short* __restr
 // Elementwise activation on bf16, 8 elements per thread: out = act(x [+ y]); out may alias x.
 // kind 0 = exact-erf GELU (nn.GELU: OpenCLIP ViT-H/14, the ViT-B of MiDaS), 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI
 // ViT-L/14), 2 = ReLU (BiT bottlenecks and the fusion blocks of MiDaS DPT-hybrid), 3 = identity (a plain add)
-__global__ void add_act_bf16_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y, uint4* __restrict__ out, long n8, int kind) {
+__global__ void add_act_bf16_kernel(const uint4* x, const uint4* __restrict__ y, uint4* out, long n8, int kind) {   // (out may be x)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const uint4 v = x[i];
     unsigned int u[4] = {v.x, v.y, v.z, v.w};
