@@ -355,3 +355,28 @@ def test_depth_embedder_mirror_names_match_reference():
     assert len(cfgs) == 1
     emb = instantiate_from_config(cfgs[0])
     assert isinstance(emb, DepthEmbedder) and not isinstance(emb, _Unavailable) and emb.shuffle_size == 3
+
+
+def test_depth_embedder_loads_midas_checkpoint(tmp_path):
+    """init_from_midas_ckpt: a DPTDepthModel state_dict as dpt_hybrid_384.pt stores it (bare keys, fp16 or fp32, optionally
+    wrapped in {'model': ...}) fills `model.model.*`; a checkpoint that lacks keys is refused."""
+    from hi3d_hip import synth
+    from hi3d_hip.runtime_dpt import dpt_hybrid_shapes
+    from sgm.util import params_key
+    from vtdm.encoders import DepthEmbedder
+    shapes = dpt_hybrid_shapes()
+    small = {k: s for k, s in shapes.items() if "blocks." not in k or ".blocks.0." in k}      # keep the file small: a subset ...
+    sd = synth.synth_state_dict(small, 9)
+    e = DepthEmbedder()
+    full = {k: v.clone() for k, v in e.model.model.state_dict().items()}
+    full.update({k: v.half() for k, v in sd.items()})                                          # ... over the module's own values
+    path = str(tmp_path / "dpt.pt")
+    torch.save({"model": full}, path)
+    before = params_key(e.model, "cpu")
+    e.init_from_midas_ckpt(path)
+    got = e.state_dict()
+    assert all(torch.equal(got["model.model." + k], v.half().float()) for k, v in sd.items())
+    assert params_key(e.model, "cpu") != before                  # the runtime will re-pack
+    torch.save({k: v for k, v in full.items() if "scratch.refinenet1" not in k}, path)
+    with pytest.raises(KeyError, match="lacks"):
+        e.init_from_midas_ckpt(path)
