@@ -12,6 +12,10 @@ timing : the K timed steps run the product path -- one HIP-graph replay per step
          (hi3d_hip/fused_step.py).  Kernels inside a graph cannot be bracketed by events, so the
          per-kernel HIP-event breakdown (`roofline`, `kernels_ms_per_step`) is taken over the K steps
          that FOLLOW the timed region, same inputs and same kernels launched eagerly on the same stream.
+legs   : with the default arguments at N = 1 the headline line also carries `legs` -- the other BASELINE.json
+         configurations measured by the same code on the same box, each with its own executed-FLOP roofline:
+         stage 1 (config 2: 16 views @ 512^2), stage 2 at 32 views (config 4), stage 2 with the fp8 score product
+         (config 5) and the first-stage decode of the clip.  `--no-legs` skips them.
 N > 1  : one process per GPU (torchrun); every rank denoises an independent orbit clip
          (replicas -- the unit that shards with no data-path collective, SURVEY 8e);
          value = steps of all ranks / max-over-ranks time; "scaling": "weak".
@@ -40,8 +44,13 @@ def unet_cfg(stage, mc=320):
                 adm_in_channels=768 if stage == 1 else 512, use_checkpoint=True)
 
 
-# algorithmic work per denoise step of the reference-equivalent graph
+# algorithmic work per denoise step of the reference-equivalent graph, and the part of it this
+# framework executes: the single-key cross-attention (softmax == 1) is eliminated algebraically, SURVEY 8d asks for
+# utilisation against the EXECUTED work when that is the case.  The executed figure is counted per launch by the
+# profiler (ops.Profiler: 2 M N K per GEMM / conv, 4 b h n m d per attention); these constants are the same count,
+# used only when the per-kernel profile is switched off.
 STEP_TFLOP = {1: 40.61, 2: 209.47}
+STEP_TFLOP_EXECUTED = {1: 39.3, 2: 202.7}
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -63,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
+    ap.add_argument("--no-legs", action="store_true", help="N = 1 headline run: skip the extra legs (stage 1, 32 views, fp8 scores, VAE decode)")
+    ap.add_argument("--leg-steps", type=int, default=6)
     ap.add_argument("--no-clip-parallel", action="store_true",
                     help="N > 1: skip the extra leg that runs ONE clip over all GPUs (CFG split x frame<->space all-to-all, RCCL)")
     a = ap.parse_args()
@@ -82,18 +93,89 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if a.config == "vae":
+        res = bench_vae(a, rank, world, dev, use_dist, a.steps, a.warmup)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if use_dist:
+            torch.distributed.destroy_process_group()
+        return
+    stage = 1 if a.config == "s1" else 2
+    out, unet, sampler, ms_per_step = unet_bench(a, stage, a.views, a.attn, rank, world, dev, use_dist, a.steps, a.warmup,
+                                                 profile=not a.no_profile, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline))
+    headline = stage == 2 and a.views == 16 and a.attn == "bf16"
+    if headline and world == 1 and not use_dist and not a.no_legs:
+        del unet, sampler
+        out["legs"] = run_legs(a, rank, world, dev)
+        unet = sampler = None
+    if use_dist and world > 1 and not a.no_clip_parallel:
+        # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
+        # single 16/32-view clip faster (SURVEY 8e): CFG pair x frame<->space groups, all collectives over RCCL
+        # ... and never lose the headline line to it: a Python error is caught, and a watchdog prints the line and ends the
+        # process if the leg does not come back (a stuck collective cannot be interrupted from Python)
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["clip_parallel"] = {"error": "timed out (watchdog); headline numbers above are unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(max(90.0, 40.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            out["clip_parallel"] = clip_parallel_leg(a, unet, sampler, stage, a.views, 64 if stage == 1 else 128, dev, world, ms_per_step)
+        except Exception as e:
+            out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+        wd.cancel()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        if "error" in out.get("clip_parallel", {}):
+            sys.stdout.flush()
+            os._exit(0)                  # ranks may have diverged inside the optional leg: do not wait on a teardown barrier
+        torch.distributed.destroy_process_group()
+
+
+def run_legs(a, rank, world, dev):
+    """The other BASELINE.json configurations, measured by the same code right after the headline (N = 1 only).
+    Each leg is one dict: ms_per_step, value (steps/s or frames/s), executed TFLOP per step and the roofline on them.
+    A failing leg is reported as {"error": ...}; the headline line is already complete at that point."""
+    import gc
+    legs = {}
+    plan = (("s1_16views_512", dict(stage=1, T=16, attn="bf16")),        # BASELINE config 2
+            ("s2_32views_1024", dict(stage=2, T=32, attn="bf16")),       # config 4
+            ("s2_16views_fp8qk", dict(stage=2, T=16, attn="fp8qk")))     # config 5 (fp8 score product, own tolerance)
+    for name, kw in plan:
+        gc.collect(); torch.cuda.empty_cache()
+        try:
+            o, u, sm, _ = unet_bench(a, kw["stage"], kw["T"], kw["attn"], rank, world, dev, False, a.leg_steps, 3, profile=True, cpu=False)
+            del u, sm
+            legs[name] = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "step_roofline",
+                                            "roofline", "kernels_ms_per_step") if k in o}
+            legs[name]["workload"] = o["config"]["workload"]
+        except Exception as e:                      # noqa: BLE001
+            legs[name] = {"error": f"{type(e).__name__}: {e}"}
+    gc.collect(); torch.cuda.empty_cache()
+    try:
+        r = bench_vae(a, rank, world, dev, False, 1, 1)
+        legs["vae_decode_16x1024"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_frame", "dtype",
+                                                        "roofline", "kernels_ms_per_frame")}
+    except Exception as e:                          # noqa: BLE001
+        legs["vae_decode_16x1024"] = {"error": f"{type(e).__name__}: {e}"}
+    return legs
+
+
+def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, profile, cpu):
+    """One sampler-step benchmark: `warmup` untimed steps, `steps` timed steps of the product path (graph replay), then the
+    per-kernel eager profile.  Returns (json dict, unet, sampler, ms_per_step)."""
     from hi3d_hip import ops, synth
     from sgm.modules.diffusionmodules.denoiser import Denoiser
     from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
-    if a.config == "vae":
-        return bench_vae(a, rank, world, dev, use_dist)
-    if a.attn == "fp8qk":
-        os.environ["HI3D_ATTN_FP8QK"] = "1"
-    stage = 1 if a.config == "s1" else 2
-    T = a.views
+    os.environ["HI3D_ATTN_FP8QK"] = "1" if attn == "fp8qk" else "0"       # read when the runtime is built
     lat = 64 if stage == 1 else 128
     cfg = unet_cfg(stage)
     t0 = time.time()
@@ -104,7 +186,7 @@ def main():
     ParamTree.skip_init = False
     synth.fill_module_on_device_(unet, seed=1, prefix="model.diffusion_model.")
     cpu_sd = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if cpu:
         cpu_sd = {"model.diffusion_model." + k: v.float().cpu() for k, v in unet.state_dict().items()}
     model = OpenAIWrapper(unet)
     unet.runtime(dev)                      # one-time weight re-layout
@@ -135,11 +217,11 @@ def main():
         if use_dist:
             torch.distributed.barrier()
 
-    for i in range(max(a.warmup, 3)):           # >= 3: the third fused step captures the HIP graph
+    for i in range(max(warmup, 3)):           # >= 3: the third fused step captures the HIP graph
         x = step(i, x)
     barrier(); torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
+    for i in range(warmup, warmup + steps):
         x = step(i, x)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t_start
@@ -148,28 +230,28 @@ def main():
     steppers = list(unet.runtime(dev).steppers.values())
     graphed = bool(steppers) and steppers[0].graph is not None
     # per-kernel breakdown: the same K steps again, launched eagerly with HIP events around every kernel
-    prof = None if a.no_profile else ops.Profiler()
+    prof = ops.Profiler() if profile else None
     if prof is not None:
         ops.PROFILER = prof
         t_p = time.perf_counter()
-        for i in range(a.warmup, a.warmup + a.steps):
+        for i in range(warmup, warmup + steps):
             x = step(i, x)
         torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - t_p) / a.steps * 1e3
+        eager_ms = (time.perf_counter() - t_p) / steps * 1e3
         ops.PROFILER = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
 
-    ms_per_step = elapsed / a.steps * 1e3
-    value = world * a.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    value = world * steps / elapsed
     out = {
         "metric": "denoise-steps/sec (UNet fwd) at 16 views x 1024^2" if stage == 2 and T == 16
                   else f"denoise-steps/sec (UNet fwd) at {T} views x {lat * 8}^2",
-        "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if a.attn == "bf16" else "fp8-qk/bf16", "data": "synthetic",
+        "dtype": "bf16" if attn == "bf16" else "fp8-qk/bf16", "data": "synthetic",
         "config": {"workload": f"Hi3D stage-{stage} VideoUNet sampler step, {T} views @ {lat * 8}x{lat * 8} "
                                f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
                                "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
@@ -177,26 +259,30 @@ def main():
                    "step_launch": "one HIP-graph replay per step" if graphed else "eager kernel launches"},
     }
     step_tf = STEP_TFLOP[stage] * (T / 16.0)
-    out["step_roofline"] = {"bound": "mfma", "achieved": round(step_tf / (ms_per_step / 1e3), 1),
+    summ = prof.summary() if prof is not None else None
+    # executed work per step: what the kernels of this step actually compute (per-launch count of the profiled steps)
+    exec_tf = (sum(d["flops"] for d in summ.values()) / steps / 1e12) if summ else STEP_TFLOP_EXECUTED[stage] * (T / 16.0)
+    out["step_roofline"] = {"bound": "mfma", "achieved": round(exec_tf / (ms_per_step / 1e3), 1),
                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(step_tf / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
-                            "note": "whole step: reference-equivalent algorithmic TFLOP / wall time"}
+                            "frac": round(exec_tf / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
+                            "executed_tflop_per_step": round(exec_tf, 2), "reference_graph_tflop_per_step": round(step_tf, 2),
+                            "note": "whole step: EXECUTED TFLOP (reference graph minus the algebraically eliminated single-key "
+                                    "cross-attention, SURVEY 8d) / wall time"}
     if prof is not None:
-        summ = prof.summary()
         total_ms = sum(d["ms"] for d in summ.values())
         fams = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
         for fam, d in fams:
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-            log(f"[bench] {fam:16s} {d['ms'] / a.steps:9.3f} ms/step  {d['launches'] // a.steps:4d} launches/step  "
+            log(f"[bench] {fam:16s} {d['ms'] / steps:9.3f} ms/step  {d['launches'] // steps:4d} launches/step  "
                 f"{tf:8.1f} TFLOP/s  {gbs:8.1f} GB/s(alg)")
-        log(f"[bench] kernels total {total_ms / a.steps:.2f} ms/step; wall {ms_per_step:.2f} ms/step "
+        log(f"[bench] kernels total {total_ms / steps:.2f} ms/step; wall {ms_per_step:.2f} ms/step "
             f"({'graph replay' if graphed else 'eager'}), {eager_ms:.2f} ms/step eager with events")
         if a.shapes:
             for fam, d in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:40]:
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                log(f"[bench]   {fam:60s} {d['ms'] / a.steps:8.3f} ms/step {d['launches'] // a.steps:4d}x "
+                log(f"[bench]   {fam:60s} {d['ms'] / steps:8.3f} ms/step {d['launches'] // steps:4d}x "
                     f"{d['ms'] / d['launches']:7.3f} ms each {tf:7.1f} TFLOP/s {gbs:7.0f} GB/s(alg)")
         # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
         g = [d for f, d in summ.items() if f.startswith("gemm_")]   # (the fused feed-forward kernel is listed on its own line)
@@ -209,17 +295,17 @@ def main():
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py);
         # measured offline because counters serialise kernels -- null if no profile is committed
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{a.config}.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{('s1' if stage == 1 else 's2')}.json")
+        if os.path.exists(tpath) and T == 16 and attn == "bf16":      # the PMC passes were taken on this configuration
             traffic = json.load(open(tpath)).get("gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel", {}).get("bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                           "launches_per_step": k_n // a.steps, "avg_launch_ms": round(k_ms / k_n, 4),
-                           "share_of_step": round(k_ms / a.steps / ms_per_step, 3),
-                           "timing": f"HIP events around every launch over the {a.steps} steps after the timed region "
+                           "launches_per_step": k_n // steps, "avg_launch_ms": round(k_ms / k_n, 4),
+                           "share_of_step": round(k_ms / steps / ms_per_step, 3),
+                           "timing": f"HIP events around every launch over the {steps} steps after the timed region "
                                      "(the timed steps are graph replays)"}
-        out["kernels_ms_per_step"] = {f: round(d["ms"] / a.steps, 3) for f, d in fams}
+        out["kernels_ms_per_step"] = {f: round(d["ms"] / steps, 3) for f, d in fams}
         for fam in ("attn_d64", "attn_d64_fp8qk"):
             if fam not in summ:
                 continue
@@ -231,39 +317,13 @@ def main():
                 d = summ[fam]
                 out[fam + "_hbm"] = {"achieved": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                      "unit": "GB/s", "frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        step_flops_exec = sum(d["flops"] for d in summ.values()) / a.steps
+        step_flops_exec = sum(d["flops"] for d in summ.values()) / steps
     else:
         step_flops_exec = None
 
     if cpu_sd is not None:
         out["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
-    if use_dist and world > 1 and not a.no_clip_parallel:
-        # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
-        # single 16/32-view clip faster (SURVEY 8e): CFG pair x frame<->space groups, all collectives over RCCL
-        # ... and never lose the headline line to it: a Python error is caught, and a watchdog prints the line and ends the
-        # process if the leg does not come back (a stuck collective cannot be interrupted from Python)
-        import threading
-
-        def _bail():
-            if rank == 0:
-                out["clip_parallel"] = {"error": "timed out (watchdog); headline numbers above are unaffected"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        wd = threading.Timer(max(90.0, 40.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
-        wd.daemon = True
-        wd.start()
-        try:
-            out["clip_parallel"] = clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, ms_per_step)
-        except Exception as e:
-            out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
-        wd.cancel()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        if "error" in out.get("clip_parallel", {}):
-            sys.stdout.flush()
-            os._exit(0)                  # ranks may have diverged inside the optional leg: do not wait on a teardown barrier
-        torch.distributed.destroy_process_group()
+    return out, unet, sampler, ms_per_step
 
 
 def clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, replica_ms):
@@ -350,7 +410,7 @@ def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
 VAE_TFLOP_PER_FRAME = {512: 2.51, 1024: 10.47}     # decode_first_stage, BASELINE.md section 2
 
 
-def bench_vae(a, rank, world, dev, use_dist):
+def bench_vae(a, rank, world, dev, use_dist, steps, warmup):
     """decode_first_stage of one clip: `--views` frames at 1024x1024 (latent 128x128) through the full-width
     AutoencoderKL decoder, en_and_decode_n_samples_a_time = 1 as configs/inference-v02.yaml ships.
     A "step" is the decode of the whole clip; value = frames/s."""
@@ -367,13 +427,13 @@ def bench_vae(a, rank, world, dev, use_dist):
     def clip():
         return [ae.decode(z[i:i + 1]) for i in range(T)][-1]
 
-    for _ in range(max(1, a.warmup)):
+    for _ in range(max(1, warmup)):
         out = clip()
     if use_dist:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = clip()
     torch.cuda.synchronize()
     if use_dist:
@@ -386,10 +446,10 @@ def bench_vae(a, rank, world, dev, use_dist):
     assert torch.isfinite(out).all()
     prof = ops.Profiler(); ops.PROFILER = prof
     clip(); torch.cuda.synchronize(); ops.PROFILER = None
-    ms_frame = elapsed / a.steps / T * 1e3
+    ms_frame = elapsed / steps / T * 1e3
     tf = VAE_TFLOP_PER_FRAME[lat * 8]
-    res = {"metric": f"VAE decode frames/sec at {lat * 8}^2 (decode_first_stage)", "value": round(world * T * a.steps / elapsed, 3),
-           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+    res = {"metric": f"VAE decode frames/sec at {lat * 8}^2 (decode_first_stage)", "value": round(world * T * steps / elapsed, 3),
+           "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
            "ms_per_frame": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
            "config": {"workload": f"AutoencoderKL decoder (ch 128, mult 1-2-4-4), {T} frames @ {lat * 8}x{lat * 8}, one frame per call"},
@@ -403,10 +463,7 @@ def bench_vae(a, rank, world, dev, use_dist):
         log(f"[bench]   {fam:64s} {d['ms'] / T:8.3f} ms/frame {d['launches'] // T:3d}x {tfk:7.1f} TFLOP/s {gbs:7.0f} GB/s(alg)")
     fams = prof.summary()
     res["kernels_ms_per_frame"] = {f: round(d["ms"] / T, 3) for f, d in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    if use_dist:
-        torch.distributed.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

@@ -20,8 +20,39 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 RESOURCES = os.path.join(ROOT, "hi3d_hip", "kernel_resources.json")
 
 
+TORCH_LIB = os.path.join(ROOT, "hi3d_hip", "libhi3d_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
+
+
 def _sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build_torch_ops(force=False, verbose=True):
+    """libhi3d_torch.so: the TORCH_LIBRARY(hi3d, ...) shim over the C ABI (csrc/torch_ops.cpp; host-only C++, g++).
+    Linked against libhi3d_hip.so beside it ($ORIGIN rpath) and the torch libraries of THIS interpreter."""
+    import torch
+    tp = os.path.dirname(torch.__file__)
+    h = hashlib.sha256()
+    for f in (TORCH_SRC, os.path.join(ROOT, "..", "include", "hi3d_hip.h")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(torch.__version__.encode())
+    dig, stamp = h.hexdigest(), TORCH_LIB + ".stamp"
+    if not force and os.path.exists(TORCH_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return TORCH_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{tp}/include", f"-I{tp}/include/torch/csrc/api/include", "-I/opt/rocm/include", TORCH_SRC, "-o", TORCH_LIB,
+           f"-L{tp}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", f"-L{os.path.dirname(LIB)}", "-lhi3d_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("torch_ops.cpp failed to build:\n" + r.stdout.decode()[-4000:])
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    if verbose:
+        print(f"[hi3d build] {TORCH_LIB}", file=sys.stderr)
+    return TORCH_LIB
 
 
 def _digest():
@@ -107,3 +138,4 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_torch_ops(force="--force" in sys.argv)

@@ -22,7 +22,6 @@
 //     cost is the q/k/v/o traffic).
 #include "common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -45,7 +44,7 @@ constexpr int QB = 2;                  // 32-row query blocks per wave
 constexpr int Q_TILE = 4 * QB * 32;    // query rows per block
 
 // PRE: q arrives pre-multiplied by scale*log2(e) (the UNet runtime folds it into the to_q weights, one
-// rounding); otherwise the scale is applied to the fp32 scores (one packed FMA per two scores).
+// rounding); otherwise the scale is applied to the fp32 score differences (one packed multiply per two scores).
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
@@ -133,73 +132,68 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-  // Softmax bookkeeping in the log2 domain of the pre-scaled scores.  The common pass does not
-  // compute the tile maximum: P = exp2(S - m_run) is formed as each 32-key score block leaves
-  // the MFMA (which already subtracted m_run, see negm), and only the row sums (needed anyway)
-  // are checked at the end of the tile.  Softmax is invariant to the shift, so any m_run that
-  // keeps P bounded is as good as the true maximum.  When a row sum exceeds SUM_MAX (or is not
-  // finite), on the first tile and on a ragged last tile, an exact pre-pass runs first: scores,
-  // true tile maximum, reference point / O / l moved in place -- and then the same common
-  // pass.  One P register set, one PV block (two sets would be merged by ~50 register moves
-  // per tile); all branches are wave-uniform.
-  float m_run[QB], l_run[QB];
+  // Softmax bookkeeping relative to a running reference point m_ref, kept in the domain of the RAW scores
+  // q.k (PRE: q arrives pre-multiplied by scale*log2(e), so raw == log2 domain and kexp == 1; otherwise
+  // P = exp2((q.k - m_ref) * kexp) with kexp = scale*log2(e) > 0 applied to the fp32 differences).  The common
+  // pass does not compute the tile maximum: -m_ref is the C operand of each 32-key block's first score MFMA
+  // (cneg: 16 equal registers per query block), so the matrix core delivers q.k - m_ref and P costs one
+  // v_exp_f32 per score (plus one packed multiply for !PRE); only the row sums (needed anyway) are checked
+  // at the end of the tile.  Softmax is invariant to the shift, so any m_ref that keeps P bounded is as good
+  // as the true maximum.  When a row sum exceeds SUM_MAX (or is not finite), and on the first tile, an exact
+  // pre-pass runs first: scores, true tile maximum, reference point / O / l moved in place -- and then the
+  // same common pass.  One P register set, one PV block; all branches are wave-uniform.
+  //
+  // Keys beyond S_kv (a last tile with S_kv % 64 != 0) take the SAME instruction stream as every other tile:
+  // their C-operand registers are set to -inf before the block's first score MFMA, so the matrix core
+  // returns -inf, exp2 gives P = 0, and neither the maximum nor the row sum sees them.  (Round 2 peeled that
+  // tile into a second code copy with a per-score select; that copy is gone)
+  float m_ref[QB], l_run[QB];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = 0.f; l_run[qb] = 0.f; }
-  // -m_run in 16 equal registers per query block: the C operand of a tile's first score MFMA,
-  // so the subtraction costs no VALU instruction (rewritten only by the exact pre-pass)
-  f32x16 negm[QB];
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int qb = 0; qb < QB; ++qb) { m_ref[qb] = 0.f; l_run[qb] = 0.f; }
+  f32x16 cneg[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+    for (int r = 0; r < 16; ++r) cneg[qb][r] = 0.f;
+  const float kexp = PRE ? 1.0f : p.scale_log2;
 
   const int ntile = (p.Skv + KV_TILE - 1) / KV_TILE;
-  const int nfull = p.Skv / KV_TILE;                   // a ragged last tile (keys >= Skv to mask) is peeled off
-  // one key tile; RAGGED is a compile-time flag so that the mask's index arithmetic exists only
-  // in the peeled copy (left in the loop it was hoisted and ran on every tile: ~70 instructions)
-  auto tile = [&](const int j, auto ragged_tag) {
-    constexpr bool ragged = decltype(ragged_tag)::value;
+  const int nfull = p.Skv / KV_TILE;                   // j == nfull < ntile: the tile with keys >= S_kv
+  issue(0, 0);
+  for (int j = 0; j < ntile; ++j) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (j + 1 < ntile) issue(j + 1, (j & 1) ^ 1);
+    const bool tail = (j == nfull);                    // wave-uniform; true at most once
 
-    // S^T - m = K Q^T - m for 32 keys x the wave's 64 query rows: every K fragment feeds QB MFMAs.
+    // q.k - m_ref for 32 keys x the wave's 64 query rows: every K fragment feeds QB MFMAs.
     // lane registers: sc[qb][r] = score of key  j*64 + kb*32 + (r>>3)*16 + hi*8 + (r&7)
     auto scores = [&](const int kb, f32x16 (&sc)[QB]) {
+      if (tail) {
+        // -inf into the C registers of keys >= S_kv, -m_ref into the others (rebuilt from m_ref on every
+        // call: the two key blocks of the tile have different masks).  `rem` passes through an empty asm so
+        // that the compare / select chain stays inside this block (hoisted, it ran on every tile).
+        int rem = p.Skv - j * KV_TILE;
+        asm volatile("" : "+s"(rem));
+        const int lim = rem - kb * 32 - hi * 8;        // register r is beyond S_kv iff (r>>3)*16 + (r&7) >= lim
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cneg[qb][r] = ((r >> 3) * 16 + (r & 7) >= lim) ? -INFINITY : -m_ref[qb];
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(k_ptr[ks] + kb * 32 * 128);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
-          sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? (PRE ? negm[qb] : zero16) : sc[qb], 0, 0, 0);
-      }
-      if (!PRE) {                                // scores -> log2 domain, relative to the reference point
-        const hi3d_f2 c2 = hi3d_f2{p.scale_log2, p.scale_log2};
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          const hi3d_f2 nm2 = hi3d_f2{-m_run[qb], -m_run[qb]};
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const hi3d_f2 t = hi3d_f2{sc[qb][r], sc[qb][r + 1]} * c2 + nm2;
-            sc[qb][r] = t[0]; sc[qb][r + 1] = t[1];
-          }
-        }
-      }
-      if (ragged) {
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kv = j * KV_TILE + kb * 32 + (r >> 3) * 16 + hi * 8 + (r & 7);
-            sc[qb][r] = (kv >= p.Skv) ? -INFINITY : sc[qb][r];
-          }
+          sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? cneg[qb] : sc[qb], 0, 0, 0);
       }
     };
 
     bf16x8 pf[QB][4];
     float psum[QB];
-    bool exact = (j == 0) || ragged || p.force_exact;
+    bool exact = (j == 0) || p.force_exact;
     for (;;) {
       if (exact) {
         // exact pre-pass: move the rows' reference point to the true maximum seen so far
@@ -218,14 +212,14 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           const float t = fmaxf(mx[qb], __shfl_xor(mx[qb], 32, 64));   // the row's other 32 keys of this tile
-          // t is relative to m_run (finite: every tile has >= 1 valid key); never move down,
+          // t is relative to m_ref (finite: every tile has >= 1 valid key); never move down,
           // except to establish the reference on the first tile (O = l = 0 there)
           const float d = (j == 0) ? t : fmaxf(t, 0.f);
-          const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
-          m_run[qb] += d;
+          const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d * kexp);
+          m_ref[qb] += d;
           l_run[qb] *= alpha;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) negm[qb][r] -= d;     // in place (a fresh definition costs 32 moves per tile)
+          for (int r = 0; r < 16; ++r) cneg[qb][r] -= d;     // in place (a fresh definition costs 32 moves per tile)
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -247,9 +241,11 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
             union { bf16x8 v; unsigned int u[4]; } pk;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+              hi3d_f2 x = hi3d_f2{sc[qb][half * 8 + 2 * t], sc[qb][half * 8 + 2 * t + 1]};
+              if (!PRE) x = x * hi3d_f2{kexp, kexp};             // one packed multiply per two scores
               hi3d_f2 e;
-              e[0] = __builtin_amdgcn_exp2f(sc[qb][half * 8 + 2 * t]);
-              e[1] = __builtin_amdgcn_exp2f(sc[qb][half * 8 + 2 * t + 1]);
+              e[0] = __builtin_amdgcn_exp2f(x[0]);
+              e[1] = __builtin_amdgcn_exp2f(x[1]);
               ps[qb] += e;
               pk.u[t] = pack_bf16x2(e[0], e[1]);
             }
@@ -267,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum[qb];
 
     // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile); every V^T
-    // fragment feeds QB MFMAs
+    // fragment feeds QB MFMAs.  Keys >= S_kv: P = 0 and the V^T columns are the zero padding.
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -281,10 +277,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { k_ptr[ks] += stage_step; v_ptr[ks] += stage_step; }
     stage_step = -stage_step;
-  };
-  issue(0, 0);
-  for (int j = 0; j < nfull; ++j) tile(j, std::false_type{});
-  if (nfull < ntile) tile(nfull, std::true_type{});
+  }
 
   // ---- finish: both half-waves hold partial row sums of the same query row
 #pragma unroll
@@ -458,6 +451,7 @@ extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void*
   if ((ldq % 8) || (ldk % 8) || (ldo % 4)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: leading dims must keep 16-byte rows");
   if (ld_vt % 64 || ld_vt < S_kv) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: ld_vt must be S_kv rounded up to 64");
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: misaligned pointer");
+  if (!(scale >= 0.0f)) HI3D_FAIL(HI3D_EINVAL, "attn_d64: scale must be > 0 (or 0: q already carries scale*log2(e))");
   AttnParams p;
   p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)vt; p.out = (unsigned short*)out;
   p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_vt; p.ldo = ldo;

@@ -197,6 +197,39 @@ inline void same_pad(int in, int k, int& out, int& before) {
   before = total > 0 ? total / 2 : 0;
 }
 
+
+// ------------------------------------------------------------------------------------
+// One axis of a separable image resampling with precomputed banded taps (hi3d_hip/resample.py):
+//   out[outer][o][inner] = a[c] * sum_t w[o][t] * in[outer][start[o] + t][inner] + b[c],   c = (outer / chan_div) % chan_mod
+// Replaces kornia.geometry.resize (bicubic, align_corners, antialias: Gaussian blur folded into the taps) in
+// FrozenOpenCLIPImageEmbedder.preprocess (sgm/modules/encoders/modules.py:619-628) and F.interpolate(bilinear) in
+// AesEmbedder.forward (vtdm/encoders.py:80-83), together with their (x + 1) / 2 and mean / std normalisation (the
+// per-channel affine of the second pass).  Thread = one output element, `inner` fastest (coalesced for the H pass;
+// the W pass, inner == 1, reads ~ntap contiguous floats per thread).
+__global__ __launch_bounds__(256) void resample_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const int* __restrict__ start, const float* __restrict__ w,
+                                                            int ntap, long total, int n_in, int n_out, int inner,
+                                                            const float* __restrict__ a, const float* __restrict__ b,
+                                                            int chan_div, int chan_mod) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int i = (int)(idx % inner);
+  const long r = idx / inner;
+  const int o = (int)(r % n_out);
+  const long ou = r / n_out;
+  const float* src = in + (ou * n_in + start[o]) * inner + i;
+  const float* wo = w + (long)o * ntap;
+  const int lim = n_in - start[o];                 // taps beyond the input carry zero weight; do not touch memory there
+  float acc = 0.f;
+  for (int t = 0; t < ntap; ++t)
+    if (t < lim) acc += wo[t] * src[(long)t * inner];
+  if (a) {
+    const int c = (int)((ou / chan_div) % chan_mod);
+    acc = acc * a[c] + b[c];
+  }
+  out[idx] = acc;
+}
+
 }  // namespace
 
 extern "C" int hi3d_dpt_stem_conv(const float* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, void* stream) {
@@ -268,6 +301,21 @@ extern "C" int hi3d_depth_normalize_unshuffle(const float* d, float* out, int32_
   if (B <= 0 || Hs <= 0 || Ws <= 0 || s <= 0) HI3D_FAIL(HI3D_EINVAL, "depth_normalize_unshuffle: non-positive size");
   if (Hs % s || Ws % s) HI3D_FAIL(HI3D_ESHAPE, "depth_normalize_unshuffle: size not a multiple of the shuffle size");
   hipLaunchKernelGGL(depth_normalize_unshuffle_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, d, out, Hs, Ws, s);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_resample_axis(const float* in, float* out, const int32_t* start, const float* w, int32_t ntap,
+                                  int64_t outer, int32_t n_in, int32_t n_out, int32_t inner, const float* scale,
+                                  const float* shift, int32_t chan_div, int32_t chan_mod, void* stream) {
+  if (!in || !out || !start || !w) HI3D_FAIL(HI3D_EINVAL, "resample_axis: null pointer");
+  if (ntap <= 0 || outer <= 0 || n_in <= 0 || n_out <= 0 || inner <= 0) HI3D_FAIL(HI3D_EINVAL, "resample_axis: non-positive size");
+  if ((scale == nullptr) != (shift == nullptr)) HI3D_FAIL(HI3D_EINVAL, "resample_axis: scale and shift come together");
+  if (scale && (chan_div <= 0 || chan_mod <= 0)) HI3D_FAIL(HI3D_EINVAL, "resample_axis: bad channel decomposition");
+  const long total = (long)outer * n_out * inner;
+  if ((total + 255) / 256 > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "resample_axis: grid too large");
+  hipLaunchKernelGGL(resample_axis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     (const int*)start, w, ntap, total, n_in, n_out, inner, scale, shift, chan_div, chan_mod);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

@@ -130,7 +130,8 @@ __global__ void cfg_update_x_kernel(const float* __restrict__ x, unsigned short*
 }
 
 // hi3d_sampler_step with sigma / sigma_next in device memory and an explicit output (may alias x)
-__global__ void sampler_step_dev_kernel(const float* __restrict__ x, float* __restrict__ xo,
+// (x and xo carry no __restrict__: FusedStepper passes the same buffer for both)
+__global__ void sampler_step_dev_kernel(const float* x, float* xo,
                                         const float* __restrict__ net, const float* __restrict__ scale,
                                         const float* __restrict__ sig, int T, int HW, int ldn) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

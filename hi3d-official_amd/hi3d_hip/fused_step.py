@@ -104,8 +104,8 @@ class FusedStepper:
         self.sig = torch.zeros(2, device=dev, dtype=torch.float32)                          # sigma_i, sigma_{i+1}
         self.tvec = torch.zeros(2 * T, device=dev, dtype=torch.float32)                     # c_noise per batch row
         self.x = torch.zeros((T, 4, H, W), device=dev, dtype=torch.float32)                 # latent state of the graph
-        self.scale = None
-        self._scale_key = None
+        self.scale = torch.zeros(T, device=dev, dtype=torch.float32)                        # guidance scale per frame: the graph holds
+        self._scale_src = None                                                              # THIS buffer, refreshed in place
         self._concat = None            # (concat_c, version, concat_uc, version): what self.tok currently holds
         self.merged = {}               # key -> (c tensor, ver, uc tensor, ver, cat(uc, c))
         self.graph = None
@@ -131,10 +131,15 @@ class FusedStepper:
             f32 = lambda t: None if t is None else t.to(self.rt.dev, torch.float32).contiguous()
             ops.cfg_prepare(self.x, f32(cu), f32(cc), CIN_PAD, 0.0, out=self.tok)    # conditioning channels, once per clip
             self._concat = k if k is not None else (None,)
-        sk = (g.min_scale, g.max_scale, g.num_frames)
-        if self._scale_key != sk:
-            self.scale = g.scale.reshape(-1).to(self.rt.dev, torch.float32).contiguous()
-            self._scale_key = sk
+        # guider.scale is re-read whenever the tensor the guider holds is another one or was written to (a second
+        # sampler on the same model, a CFG sweep, a direct assignment): copied INTO the buffer the captured graph reads
+        gs = g.scale
+        if self._scale_src is None or self._scale_src[0] is not gs or self._scale_src[1] != gs._version:
+            flat = gs.reshape(-1)
+            if flat.numel() != self.T:
+                raise ValueError(f"guider.scale has {flat.numel()} entries for {self.T} frames")
+            self.scale.copy_(flat.to(self.rt.dev, torch.float32))
+            self._scale_src = (gs, gs._version)
         ctx = self._cat("crossattn", c["crossattn"], uc["crossattn"])
         y = self._cat("vector", c["vector"], uc["vector"])
         return self.rt.clip_consts(ctx, y, ioi, 2 * self.T, self.T)

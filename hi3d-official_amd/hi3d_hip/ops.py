@@ -430,6 +430,25 @@ def resize_bilinear(x, Ho, Wo, align_corners=False):
     return y
 
 
+def resample_image(x, kind, scale=None, shift=None):
+    """x fp32 [N, C, H, W] -> fp32 [N, C, Ho, Wo]: the separable resampling `kind` of hi3d_hip/resample.py (two banded
+    passes, W then H) followed by the per-channel affine y * scale[c] + shift[c] (fused into the second pass)."""
+    from . import resample
+    _chk_dev(x, scale, shift)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise _l.Hi3dError("resample_image: fp32 [N,C,H,W] required")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    (sh, wh), (sw, ww), (Ho, Wo) = resample.tables(kind, H, W, x.device)
+    tmp = torch.empty((N, C, H, Wo), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_resample_axis(_p(x), _p(tmp), _p(sw), _p(ww), ww.shape[1], N * C * H, W, Wo, 1, 0, 0, 1, 1, _stream()),
+             "hi3d_resample_axis")
+    y = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_resample_axis(_p(tmp), _p(y), _p(sh), _p(wh), wh.shape[1], N * C, H, Ho, Wo, _p(scale), _p(shift), 1, C,
+                                     _stream()), "hi3d_resample_axis")
+    return y
+
+
 def dpt_head_out(x, w, b):
     """x bf16 [M, C], w fp32 [C], b float -> fp32 [M]: relu(b + w . relu(x[m]))."""
     _chk_dev(x, w)

@@ -186,6 +186,9 @@ class FrameSpaceGroup:
         return t
 
 
+_SP_GROUPS = {}     # member ranks -> process group (one communicator per distinct frame-parallel group)
+
+
 class ClipParallelStepper:
     """ONE clip's Euler-EDM + CFG step on cfg x sp GPUs (the recommended 8-GPU mapping is
     2 (CFG pair) x 4 (frame <-> space groups)).  Rank r of `group` is (half, part) = divmod(r, sp):
@@ -199,7 +202,7 @@ class ClipParallelStepper:
 
     x / the returned latent are the FULL [T,4,h,w] fp32 state (replicated, 4 MB at stage 2)."""
 
-    def __init__(self, unet, guider, T, cfg=2, group=None):
+    def __init__(self, unet, guider, T, cfg=2, group=None, sp_group=None):
         from . import ops  # noqa: F401  (needs the HIP library: GPU only)
         self.unet, self.guider, self.T, self.cfg = unet, guider, T, cfg
         self.group = group
@@ -208,13 +211,17 @@ class ClipParallelStepper:
             raise ValueError(f"cfg split {cfg} does not divide the group of {world} ranks")
         self.sp = world // cfg
         self.half, self.part = divmod(rank, self.sp)
-        # one sub-group per CFG half for the frame<->space traffic (every rank must create every group)
-        self.sp_group = None
+        # one sub-group per CFG half for the frame<->space traffic.  Created with group-local synchronisation: only the
+        # MEMBERS of a sub-group call new_group, so `group` may itself be a proper sub-group of the job (e.g. 2 clips x 4
+        # GPUs) without the ranks outside it having to make a matching call; cached per member list (steppers built one
+        # after another on the same ranks share their communicators).  `sp_group=` hands in a group made elsewhere.
         ranks_all = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-        for h in range(cfg):
-            g = dist.new_group([ranks_all[h * self.sp + q] for q in range(self.sp)])
-            if h == self.half:
-                self.sp_group = g
+        mine = tuple(ranks_all[self.half * self.sp + q] for q in range(self.sp))
+        if sp_group is None:
+            sp_group = _SP_GROUPS.get(mine)
+            if sp_group is None:
+                sp_group = _SP_GROUPS[mine] = dist.new_group(list(mine), use_local_synchronization=True)
+        self.sp_group = sp_group
         self.comm = FrameSpaceGroup(T, self.sp_group)
         self.gather_bytes = 0
         self._host_staged = dist.get_backend(group) == "gloo"

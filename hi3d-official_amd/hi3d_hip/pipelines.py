@@ -1,5 +1,6 @@
-"""The two Hi3D denoising procedures as functions of an engine and PRECOMPUTED conditioning
-(`c`, `uc` come from the once-per-clip conditioner, which is outside this framework):
+"""The two Hi3D denoising procedures as functions of an engine and its conditioning (`c`, `uc`: the output of
+`model.conditioner.get_unconditional_conditioning(...)` -- the once-per-clip conditioner of sgm/modules/encoders and
+vtdm/encoders.py, which runs on the same kernels -- or synthetic dicts of the same shapes, hi3d_hip.synth.synth_conditioning):
 
   stage1_denoise  -- pipeline_i2v_eval_v01.py:62-98   (noise -> 25 Euler-EDM steps -> VAE decode)
   stage2_refine   -- pipeline_i2v_eval_v02.py:77-141  (per-frame VAE encode of the stage-1 video,

@@ -89,16 +89,19 @@ class UNetRuntime:
         # HI3D_PACK_CACHE=<dir>: keep / reuse the re-laid-out weights on disk (hi3d_hip/relayout_cache.py)
         cache_dir = os.environ.get("HI3D_PACK_CACHE") if cache_dir is None else cache_dir
         self.packed_from_cache = False
-        if cache_dir:
-            from . import relayout_cache as rc
-            fp = rc.fingerprint(state_dict, self.cfg, prefix)
-            path = rc.cache_path(cache_dir, fp)
-            self.packed_from_cache = rc.load_into(self, path, fp)
-            if not self.packed_from_cache:
+        import contextlib
+        # packing runs with this runtime's GPU as the current device (a model on cuda:1 built from a process on cuda:0)
+        with (torch.cuda.device(self.dev) if self.dev.type == "cuda" else contextlib.nullcontext()):
+            if cache_dir:
+                from . import relayout_cache as rc
+                fp = rc.fingerprint(state_dict, self.cfg, prefix)
+                path = rc.cache_path(cache_dir, fp)
+                self.packed_from_cache = rc.load_into(self, path, fp)
+                if not self.packed_from_cache:
+                    self._pack(state_dict, prefix)
+                    rc.save(self, path, fp)
+            else:
                 self._pack(state_dict, prefix)
-                rc.save(self, path, fp)
-        else:
-            self._pack(state_dict, prefix)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, sd, P):

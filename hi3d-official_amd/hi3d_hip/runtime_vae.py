@@ -13,6 +13,8 @@ of one 1024x1024 frame is affordable and both products then run on the tuned GEM
 Frames are independent: decode() can be called on any slice of the clip (frame sharding
 across GPUs, all-gather of the decoded frames afterwards).
 """
+import functools
+
 import torch
 
 from . import ops, pack
@@ -20,7 +22,21 @@ from . import ops, pack
 CZ_PAD = 64
 
 
+def _on_own_device(fn):
+    """Run a runtime method with the runtime's GPU as the current device: the kernels launch on the CURRENT device's
+    stream, so a model living on cuda:1 in a process whose current device is cuda:0 must switch for the call."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = getattr(self, "dev", None) or torch.device(args[2] if len(args) > 2 else kwargs["device"])
+        if dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class VAEDecoderRuntime:
+    @_on_own_device
     def __init__(self, state_dict, ddconfig, device, prefix=""):
         self.dd, self.dev = dict(ddconfig), torch.device(device)
         dd = self.dd
@@ -105,6 +121,7 @@ class VAEDecoderRuntime:
             ops.gemm(pr, vt[f], M=S, N=C, K=S_pad, lda=S_pad, ldw=S_pad, out=o[f * S:(f + 1) * S])
         return ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x)
 
+    @_on_own_device
     @torch.no_grad()
     def decode(self, z):
         """z: [N, Cz, h, w] latents already divided by scale_factor -> fp32 [N, out_ch, 8h, 8w]."""
@@ -148,6 +165,7 @@ class VAEEncoderRuntime(_ResnetMixin):
     DiagonalGaussianRegularizer (models/autoencoder.py:468-488, regularizers/__init__.py:21-31).
     The stride-2 Downsample pads bottom/right only (model.py:76-90): `pad_br_only` conv."""
 
+    @_on_own_device
     def __init__(self, state_dict, ddconfig, device, prefix=""):
         self.dd, self.dev = dict(ddconfig), torch.device(device)
         dd = self.dd
@@ -186,13 +204,18 @@ class VAEEncoderRuntime(_ResnetMixin):
         W["norm_out.g"] = f32(E + "norm_out.weight"); W["norm_out.b"] = f32(E + "norm_out.bias")
         self.zc = dd["z_channels"]
         W["conv_out.w"] = pack.pack_conv3x3(g(E + "conv_out.weight")); W["conv_out.b"] = f32(E + "conv_out.bias")
-        W["q.w"] = f32("quant_conv.weight").reshape(2 * self.zc, -1).contiguous(); W["q.b"] = f32("quant_conv.bias")
+        if (P + "quant_conv.weight") in sd:
+            W["q.w"] = f32("quant_conv.weight").reshape(2 * self.zc, -1).contiguous(); W["q.b"] = f32("quant_conv.bias")
+        else:                                   # AutoencodingEngine (models/autoencoder.py:96-210) has no quant convs
+            W["q.w"] = torch.eye(2 * self.zc, device=dev); W["q.b"] = torch.zeros(2 * self.zc, device=dev)
         self.W = W
 
+    @_on_own_device
     @torch.no_grad()
-    def encode(self, x, noise=None):
+    def encode(self, x, noise=None, moments=False):
         """x: [N, 3, H, W] in [-1, 1] -> z fp32 [N, Cz, H/8, W/8]; `noise` (same shape as z)
-        selects posterior.sample(), None the mode."""
+        selects posterior.sample(), None the mode.  moments=True: the encoder's raw output [N, 2 Cz, H/8, W/8]
+        (AutoencodingEngine.encode(unregularized=True), models/autoencoder.py:201-203)."""
         W = self.W
         N, _, H, Wd = x.shape
         h = ops.nchw_to_tokens(x.to(self.dev), CZ_PAD)
@@ -214,6 +237,8 @@ class VAEEncoderRuntime(_ResnetMixin):
         h = self._resnet("mid.block_2", h, N, H, Wd, cin, cin)
         h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6)
         mom = self._conv(h, "conv_out", N, H, Wd, cin, 2 * self.zc, out_fp32=True)
+        if moments:
+            return ops.tokens_to_nchw(mom, N, 2 * self.zc, H, Wd, mom.shape[-1])
         if noise is not None:
             noise = noise.to(self.dev, torch.float32).contiguous()
         return ops.vae_posterior(mom, W["q.w"], W["q.b"], noise, N, self.zc, H, Wd)
@@ -228,6 +253,7 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
     followed by a 3-channel Conv3d (3,1,1).  Same kernels as the UNet's time_stack: the frame
     axis is indexed inside the conv / norm kernels, nothing is permuted."""
 
+    @_on_own_device
     def __init__(self, state_dict, ddconfig, device, prefix=""):
         super().__init__(state_dict, ddconfig, device, prefix)
         dev, sd, P = self.dev, state_dict, prefix
@@ -262,6 +288,7 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
         return ops.gemm(h, W[q + ".out_layers.3.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
                         a1=a1, R2=xs, rows_per_group=HW, convt3=tg)
 
+    @_on_own_device
     @torch.no_grad()
     def decode(self, z, timesteps=None):
         N = z.shape[0]

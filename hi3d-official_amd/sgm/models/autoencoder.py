@@ -201,4 +201,19 @@ class AutoencodingEngine(torch.nn.Module):
 
     @torch.no_grad()
     def encode(self, x, return_reg_log=False, unregularized=False, noise=None):
-        raise NotImplementedError("AutoencodingEngine.encode: use AutoencoderKL (the encoder runtime expects quant_conv)")
+        """reference models/autoencoder.py:196-209: z = encoder(x); unregularized -> the raw moments; otherwise the
+        DiagonalGaussianRegularizer (regularizers/__init__.py:21-31): posterior.sample() -- noise drawn on the CPU generator
+        like the reference's torch.randn(...).to(device) unless `noise` is given -- or .mode() with `sample: false`."""
+        if not x.is_cuda:
+            raise RuntimeError("encode runs on the MI355X only (no CPU path in this framework)")
+        from hi3d_hip.runtime_vae import VAEEncoderRuntime
+        key = self._key(x.device)
+        if self._enc_rt is None or self._enc_key != key:
+            self._enc_rt, self._enc_key = VAEEncoderRuntime(self.state_dict(), self.encoder.ddconfig, x.device), key
+        if unregularized:
+            return self._enc_rt.encode(x, moments=True).to(x.dtype), {}
+        n, _, h, w = x.shape
+        if self.sample_posterior and noise is None:
+            noise = torch.randn((n, self.encoder.ddconfig["z_channels"], h // 8, w // 8))
+        z = self._enc_rt.encode(x, noise if self.sample_posterior else None).to(x.dtype)
+        return (z, {}) if return_reg_log else z

@@ -25,9 +25,11 @@ class LinearPredictionGuider:
         self._merged = {}
 
     def _scale_on(self, device):
-        if device not in self._scale_dev:
-            self._scale_dev[device] = self.scale.to(device)
-        return self._scale_dev[device]
+        # keyed on the tensor the attribute holds NOW (and its version): `guider.scale = ...` or an in-place edit is seen
+        m = self._scale_dev.get(device)
+        if m is None or m[0] is not self.scale or m[1] != self.scale._version:
+            m = self._scale_dev[device] = (self.scale, self.scale._version, self.scale.to(device))
+        return m[2]
 
     def __call__(self, x, sigma):
         T = self.num_frames

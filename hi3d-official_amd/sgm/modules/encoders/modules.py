@@ -1,14 +1,14 @@
-"""Conditioner container (reference: sgm/modules/encoders/modules.py:71-184).
+"""Conditioner container and embedders (reference: sgm/modules/encoders/modules.py:71-184, 570-728, 913-1046).
 
-The Hi3D conditioner runs ONCE per clip (OpenCLIP ViT-H image tower, aesthetic score, MiDaS depth, VAE
-encoder of the conditioning frame ...) and is outside the denoising hot path this
-framework covers (SURVEY.md section 8, rank-3 "next").  Built here: the scalar embedders, the
-conditioning-frame VAE embedder (it reuses the gfx950 VAE encoder) and the CLIP vision towers
-(`FrozenOpenCLIPImageEmbedder` here, `AesEmbedder` in vtdm/encoders.py, both on hi3d_hip.runtime_vit); the MiDaS
-DPT-hybrid depth tower is not.  What the hot path consumes is its
-OUTPUT: `c` / `uc` dicts with keys crossattn [B,1,1024], vector [B,adm], concat
-[T,Cc,h,w].  This container keeps the reference's combining rules for embedders that
-are available and reports the ones that are not, by name, when it is asked to run them.
+The Hi3D conditioner runs ONCE per clip.  All of its towers are built on the gfx950 kernels:
+the scalar embedders (`ConcatTimestepEmbedderND`), the conditioning-frame VAE embedder (`VideoPredictionEmbedderWithEncoder`
+on hi3d_hip.runtime_vae.VAEEncoderRuntime), the CLIP vision towers (`FrozenOpenCLIPImage(Prediction)Embedder` here,
+`AesEmbedder` in vtdm/encoders.py, both on hi3d_hip.runtime_vit) and the MiDaS DPT-hybrid depth tower (`vtdm.encoders.DepthEmbedder`
+on hi3d_hip.runtime_dpt).  open_clip / clip / timm / kornia are absent from this image: those towers and the 224 x 224 resize
+are pinned against independent implementations of the same published architectures / algorithms and declared UNPINNED
+against the packages themselves.  What the hot path consumes is the container's OUTPUT: `c` / `uc` dicts with
+keys crossattn [B,1,1024], vector [B,adm], concat [T,Cc,h,w].  An embedder whose target cannot be imported is kept as a
+named placeholder that raises when it is asked to run (`_Unavailable`).
 """
 import torch
 import torch.nn as nn
@@ -165,13 +165,20 @@ class FrozenOpenCLIPImageEmbedder(AbstractEmbModel):
             raise KeyError(f"open_clip checkpoint lacks {len(missing)} visual keys, e.g. {missing[:3]}")
 
     def preprocess(self, x):
-        """[-1,1] image -> 224 x 224 (bicubic, antialias, align_corners: kornia.geometry.resize in the reference, :618-630;
-        torch's interpolate here -- kornia is a torch wrapper and absent) -> [0,1] -> CLIP mean / std."""
+        """[-1,1] image -> 224 x 224 -> [0,1] -> CLIP mean / std (reference :619-628), on the GPU in two banded passes of
+        `hi3d_resample_axis` with the affine fused into the second: kornia.geometry.resize(bicubic, align_corners=True,
+        antialias) is kornia 0.6.9's Gaussian pre-blur + torch's bicubic, restated in hi3d_hip/resample.py (kornia itself is
+        absent from this image: unpinned against the package).  antialias=False or an up-scale: plain bicubic taps."""
+        from hi3d_hip import ops, resample
         size = self.model.cfg["image"]
-        if tuple(x.shape[-2:]) != (size, size):
-            x = torch.nn.functional.interpolate(x.float(), (size, size), mode="bicubic", align_corners=True, antialias=self.antialias)
-        x = (x + 1.0) / 2.0
-        return (x - self.mean.to(x.device).view(1, 3, 1, 1)) / self.std.to(x.device).view(1, 3, 1, 1)
+        mean, std = self.mean.to(x.device, torch.float32), self.std.to(x.device, torch.float32)
+        x = x.float()
+        if size != 224 or not self.antialias:
+            raise NotImplementedError("FrozenOpenCLIPImageEmbedder.preprocess: built for the shipped 224 x 224, antialias=True")
+        if tuple(x.shape[-2:]) == (size, size):                 # kornia returns the input untouched (affwarp.py: size == input_size)
+            return ((x + 1.0) / 2.0 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+        # ((y + 1) / 2 - mean) / std  ==  y * (0.5 / std) + (0.5 - mean) / std
+        return ops.resample_image(x, "clip224", scale=(0.5 / std).contiguous(), shift=((0.5 - mean) / std).contiguous())
 
     def forward(self, image, no_dropout=False):
         dev = image.device if image.is_cuda else torch.device(self.device)

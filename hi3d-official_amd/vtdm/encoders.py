@@ -69,10 +69,11 @@ class AesEmbedder(AbstractEmbModel):
         B, C, T, H, W = x.shape
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         y = x[:, :, T // 2].to(dev).float()
-        y = torch.nn.functional.interpolate(y, [224, 384], mode="bilinear")[:, :, :, 80:304]
-        y = (y + 1) * 0.5
-        y = (y - torch.tensor(CLIP_MEAN, device=dev).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD, device=dev).view(1, 3, 1, 1)
+        mean, std = torch.tensor(CLIP_MEAN, device=dev), torch.tensor(CLIP_STD, device=dev)
         with torch.cuda.device(dev):
+            # F.interpolate(y, [224, 384], "bilinear")[..., 80:304] -> (y + 1) / 2 -> CLIP mean / std (reference :80-83):
+            # two banded resampling passes, the crop in the column table, the affine fused into the second pass
+            y = ops.resample_image(y, "aes", scale=(0.5 / std).contiguous(), shift=((0.5 - mean) / std).contiguous())
             h = self.aesthetic_model.runtime(dev).forward(y.contiguous())     # [B, 768] fp32
             ops.l2_normalize_rows_(h)
             for wp, b, o, op, kp in self._packed_mlp(dev):

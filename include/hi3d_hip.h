@@ -357,6 +357,18 @@ int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, const void* w
                    int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
                    int32_t rows_per_group, void* stream);
 
+/* One axis of a separable image resampling with banded taps (built on the host by hi3d_hip/resample.py):
+ *   out[outer][o][inner] = scale[c] * sum_{t < ntap} w[o][t] * in[outer][start[o] + t][inner] + shift[c]
+ *   c = (outer_index / chan_div) % chan_mod ; scale == shift == NULL: no affine.  All fp32.
+ * Two passes (W then H) replace kornia.geometry.resize(x, (224, 224), "bicubic", align_corners=True,
+ * antialias=True) + (x + 1) / 2 + kornia.enhance.normalize of FrozenOpenCLIPImageEmbedder.preprocess
+ * (sgm/modules/encoders/modules.py:619-628; kornia 0.6.9's Gaussian pre-blur is folded into the taps) and
+ * F.interpolate(y, [224, 384], mode="bilinear")[..., 80:304] + the CLIP normalisation of AesEmbedder.forward
+ * (vtdm/encoders.py:80-83).  start[o] + t beyond n_in - 1 is never read (such taps carry zero weight).      */
+int hi3d_resample_axis(const float* in, float* out, const int32_t* start, const float* w, int32_t ntap,
+                       int64_t outer, int32_t n_in, int32_t n_out, int32_t inner, const float* scale,
+                       const float* shift, int32_t chan_div, int32_t chan_mod, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

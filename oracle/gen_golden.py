@@ -234,6 +234,32 @@ def gen_video_decode(name, ch, b, T, hw, wseed=1, iseed=0):
     print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
 
+def gen_engine_encode(name, ch, n, hw, wseed=1, iseed=0):
+    """AutoencodingEngine.encode (models/autoencoder.py:196-209) of the REFERENCE: raw moments (unregularized=True), the
+    sampled posterior with the CPU generator seeded, and the noise that draw used."""
+    t0 = time.time()
+    AE = ref_import.ref("sgm.models.autoencoder.AutoencodingEngine")
+    dd = vae_ddconfig(ch)
+    ae = AE(encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+            decoder_config={"target": "sgm.modules.diffusionmodules.model.Decoder", "params": dd},
+            loss_config={"target": "torch.nn.Identity"},
+            regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"}).eval()
+    synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
+    g = torch.Generator().manual_seed(iseed)
+    x = torch.rand((n, 3, hw, hw), generator=g) * 2 - 1
+    with torch.no_grad():
+        moments, _ = ae.encode(x, unregularized=True)
+        torch.manual_seed(4321)
+        z_sampled, reg_log = ae.encode(x, return_reg_log=True)
+        torch.manual_seed(4321)
+        ref_noise = torch.randn(z_sampled.shape)
+    sd = ae.state_dict()
+    fx = dict(kind="engine_encode", ddconfig=dd, weight_seed=wseed, key_prefix=VAE_PREFIX, x=x, moments=moments,
+              z_sampled=z_sampled, sample_noise=ref_noise, shapes={k: tuple(v.shape) for k, v in sd.items()})
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: moments {tuple(moments.shape)} absmax {moments.abs().max():.4f} z {tuple(z_sampled.shape)} ({time.time() - t0:.1f}s)")
+
+
 def gen_schedule(name):
     Disc = ref_import.ref("sgm.modules.diffusionmodules.discretizer.EDMDiscretization")
     Scal = ref_import.ref("sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise")
@@ -265,6 +291,7 @@ def main():
         "vae_full_lat8": lambda: gen_vae("vae_full_lat8", 128, 1, 8, iseed=2),
         "vae_enc_tiny": lambda: gen_vae_encode("vae_enc_tiny", 64, 2, 64),
         "vae_enc_full_64": lambda: gen_vae_encode("vae_enc_full_64", 128, 1, 64, iseed=4),
+        "engine_enc_tiny": lambda: gen_engine_encode("engine_enc_tiny", 64, 2, 64, iseed=8),
         "videodec_tiny": lambda: gen_video_decode("videodec_tiny", 64, 2, 3, 8),
         "videodec_full_lat8": lambda: gen_video_decode("videodec_full_lat8", 128, 1, 4, 8, iseed=3),
         "v02_tiny": lambda: gen_v02("v02_tiny", unet_cfg(2, 64), T=4, hw=8, steps=4, max_scale=2.0, iseed=6),

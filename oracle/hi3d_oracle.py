@@ -442,14 +442,40 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+def kornia_resize(img, size, interpolation="bicubic", align_corners=True, antialias=True):
+    """kornia.geometry.resize as the reference calls it (sgm/modules/encoders/modules.py:619-625) -- kornia 0.6.9
+    (environments.yaml:107), a third-party package ABSENT from this image: its published algorithm
+    (kornia/geometry/transform/affwarp.py:resize, kornia/filters/gaussian.py, kornia/filters/kernels.py:gaussian) restated;
+    parity unpinned against the package itself.  A down-scale is pre-blurred with a separable Gaussian
+    (sigma = (factor - 1) / 2 per axis, kernel size int(max(4 sigma, 3)) made odd, 'reflect' border), then
+    F.interpolate(mode, align_corners); an input already at `size` is returned untouched."""
+    h, w = img.shape[-2:]
+    if (h, w) == tuple(size):
+        return img
+    factors = (h / size[0], w / size[1])
+    if antialias and max(factors) > 1:
+        sigmas = (max((factors[0] - 1.0) / 2.0, 0.001), max((factors[1] - 1.0) / 2.0, 0.001))
+        ks = [int(max(2.0 * 2 * sigmas[0], 3)), int(max(2.0 * 2 * sigmas[1], 3))]
+        ks = [k + 1 if k % 2 == 0 else k for k in ks]
+
+        def gauss(k, sg):
+            xs = torch.arange(k, dtype=img.dtype) - k // 2
+            g = torch.exp(-xs * xs / (2.0 * sg * sg))
+            return g / g.sum()
+        ky, kx = gauss(ks[0], sigmas[0]), gauss(ks[1], sigmas[1])
+        C = img.shape[1]
+        img = F.pad(img, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+        img = F.conv2d(img, kx.view(1, 1, 1, -1).expand(C, 1, 1, -1), groups=C)       # filter2d_separable: x, then y
+        img = F.conv2d(img, ky.view(1, 1, -1, 1).expand(C, 1, -1, 1), groups=C)
+    return F.interpolate(img, size=tuple(size), mode=interpolation, align_corners=align_corners)
+
+
 def openclip_image_embedder(sd, img, heads, n_cond_frames=1, n_copies=1, prefix="open_clip.model.visual.", size=224):
     """FrozenOpenCLIPImagePredictionEmbedder (sgm/modules/encoders/modules.py:1028-1046) around
-    FrozenOpenCLIPImageEmbedder.forward (:641-692, ucg_rate 0 path): resize to 224 (bicubic, antialias), [-1,1] -> [0,1],
-    CLIP mean / std, vision tower, then "(b t) d -> b t d" and the n_copies repeat.  The reference resizes with
-    kornia.geometry.resize(align_corners=True, antialias=True); kornia is absent here, torch's bicubic + antialias is
-    used in oracle and product alike (an input already 224 x 224 is untouched by either)."""
-    if img.shape[-2:] != (size, size):
-        img = F.interpolate(img, (size, size), mode="bicubic", align_corners=True, antialias=True)
+    FrozenOpenCLIPImageEmbedder.forward (:641-692, ucg_rate 0 path): kornia resize to 224 (bicubic, align_corners,
+    antialias -- `kornia_resize` above), [-1,1] -> [0,1], CLIP mean / std, vision tower, then "(b t) d -> b t d" and the
+    n_copies repeat."""
+    img = kornia_resize(img, (size, size))
     x = (img + 1.0) / 2.0
     x = (x - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
     z = clip_visual(sd, x, heads, "gelu", prefix)

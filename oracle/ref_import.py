@@ -14,6 +14,7 @@ import sys
 import types
 
 REFERENCE_ROOT = "/root/reference"
+sys.dont_write_bytecode = True      # the reference tree is read-only: importing it must not leave __pycache__ behind
 
 
 def _stub(name, **attrs):

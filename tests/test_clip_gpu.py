@@ -120,3 +120,24 @@ def test_aes_embedder_end_to_end(dev):
         h = ops.gemm(e._split(h, kp), wp, M=4, N=op, K=3 * kp, bias=b, out_fp32=True)[:, :o].contiguous()
         r = F.linear(r, sd[f"aesthetic_mlp.layers.{i}.weight"], sd[f"aesthetic_mlp.layers.{i}.bias"])
     assert (h.cpu() - r).abs().max() < 2e-4 * max(1.0, r.abs().max().item())
+
+
+@pytest.mark.parametrize("kind,hw", [("clip224", (1024, 1024)), ("clip224", (512, 576)), ("aes", (1024, 1024)), ("aes", (320, 512))])
+def test_resample_image_matches_oracle(dev, kind, hw):
+    """hi3d_resample_axis (two banded passes + fused CLIP affine) vs the oracle's restatement of the reference's resizes:
+    kornia.geometry.resize(bicubic, align_corners, antialias) (modules.py:619-628) / F.interpolate(bilinear) + crop
+    (vtdm/encoders.py:80-83).  fp32 throughout: 1e-5 absolute on O(1) values."""
+    from oracle import hi3d_oracle as O
+    from hi3d_hip import ops
+    img = torch.rand((2, 3) + hw, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    mean, std = torch.tensor(O.CLIP_MEAN), torch.tensor(O.CLIP_STD)
+    if kind == "clip224":
+        ref = O.kornia_resize(img, (224, 224))
+    else:
+        ref = F.interpolate(img, [224, 384], mode="bilinear")[:, :, :, 80:304]
+    ref = ((ref + 1) * 0.5 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    out = ops.resample_image(img.to(dev), kind, scale=(0.5 / std).to(dev), shift=((0.5 - mean) / std).to(dev))
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    plain = ops.resample_image(img.to(dev), kind)            # no affine
+    assert (plain.cpu() * (0.5 / std).view(1, 3, 1, 1) + ((0.5 - mean) / std).view(1, 3, 1, 1) - ref).abs().max() < 1e-5

@@ -380,3 +380,45 @@ def test_depth_embedder_loads_midas_checkpoint(tmp_path):
     torch.save({k: v for k, v in full.items() if "scratch.refinenet1" not in k}, path)
     with pytest.raises(KeyError, match="lacks"):
         e.init_from_midas_ckpt(path)
+
+
+def test_resample_tap_tables_reproduce_torch_and_the_kornia_restatement():
+    """hi3d_hip/resample.py (host side of hi3d_resample_axis): the per-axis matrices equal F.interpolate, the banded
+    (start, weights) form loses nothing, and the composed CLIP resize equals the oracle's kornia 0.6.9 restatement."""
+    import torch.nn.functional as F
+    from hi3d_hip import resample as R
+    from oracle import hi3d_oracle as O
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 3, 61, 97), generator=g, dtype=torch.float64)
+    for mode, ac, (ho, wo) in (("bilinear", False, (24, 38)), ("bicubic", True, (22, 30)), ("bilinear", False, (130, 200))):
+        ref = F.interpolate(x, (ho, wo), mode=mode, align_corners=ac)
+        y = torch.einsum("oh,nchw,pw->ncop", R.interp_matrix(61, ho, mode, ac), x, R.interp_matrix(97, wo, mode, ac))
+        assert (y - ref).abs().max() < 1e-12
+    x = torch.randn((1, 3, 256, 320), generator=g, dtype=torch.float64)
+    Rh, Rw = R.kornia_axis_matrices(256, 320, (56, 56))
+    assert (torch.einsum("oh,nchw,pw->ncop", Rh, x, Rw) - O.kornia_resize(x, (56, 56))).abs().max() < 1e-12
+    for M in (Rh, Rw):
+        start, w = R.band(M)
+        assert w.shape[1] <= 14 and int(start.min()) >= 0
+        D = torch.zeros_like(M)
+        for o in range(M.shape[0]):
+            n = min(w.shape[1], M.shape[1] - int(start[o]))
+            D[o, int(start[o]):int(start[o]) + n] = w[o, :n].double()
+            assert (w[o, n:] == 0).all()                 # what lies beyond the input carries no weight
+        assert (D - M).abs().max() < 1e-7
+    # the aesthetic path's crop is a row slice of the column table
+    (sh, wh), (sw, ww), (Ho, Wo) = R.tables("aes", 512, 512, "cpu")
+    assert (Ho, Wo) == (224, 224) and ww.shape == (224, 2) or ww.shape[1] <= 3
+
+
+def test_torch_library_ops_are_registered_and_refuse_cpu_tensors():
+    """torch.ops.hi3d.* (csrc/torch_ops.cpp): every op of torch_ops.OPS has a dispatcher schema; there is no CPU kernel
+    behind them (no fallback), so a CPU tensor fails in the dispatcher instead of computing something else."""
+    from hi3d_hip import torch_ops
+    ns = torch_ops.load()
+    for name in torch_ops.OPS:
+        assert "Tensor" in str(getattr(ns, name).default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ns.self_attention(torch.zeros(4, 192, dtype=torch.bfloat16), 1, 4, 1, 0.125)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ns.layernorm(torch.zeros(4, 320, dtype=torch.bfloat16), torch.ones(320), torch.zeros(320), 1e-5)

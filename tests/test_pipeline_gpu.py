@@ -60,3 +60,88 @@ def test_stage1_clip_create_model_sample_decode(dev):
     cos = torch.nn.functional.cosine_similarity(img.flatten(), ref_img.flatten(), dim=0).item()
     print(f"pipeline: latent rel {lat_rel:.4f}  image rel {img_rel:.4f} cos {cos:.6f}")
     assert lat_rel < 6e-2 and img_rel < 8e-2 and cos > 0.998
+
+
+def test_stage2_clip_from_yaml_conditioner_encode_refine_decode(dev):
+    """ONE stage-2 clip end to end, as pipeline_i2v_eval_v02.py:77-141 runs it: create_model(inference-v02.yaml) (widths
+    reduced so the CPU oracle of the whole chain finishes in seconds) -> add_custom_cond -> GeneralConditioner (CLIP image
+    token, elevation / cond_aug embeddings, MiDaS depth unshuffle || per-frame conditioning latents) with
+    force_uc_zero_embeddings -> per-frame encode_first_stage with the posterior SAMPLED -> the re-noising blend + Euler-EDM
+    + CFG loop -> decode_first_stage.  Every stage is compared with the oracle chain run on the same draws."""
+    import math
+    from hi3d_hip import pipelines, synth
+    from oracle import hi3d_oracle as O
+    from vtdm.model import create_model
+    from conftest import shrink_conditioner
+    y = shrink_conditioner(yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v02.yaml"))))
+    P = y["model"]["params"]
+    T, steps, HW = 16, 3, 128                          # DepthEmbedder has t = 16 hard-wired (vtdm/encoders.py:34)
+    P["num_samples"] = T
+    P["network_config"]["params"]["model_channels"] = 64
+    P["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
+    P["sampler_config"]["params"]["num_steps"] = steps
+    P["sampler_config"]["params"]["verbose"] = False
+    P["sampler_config"]["params"]["guider_config"]["params"]["num_frames"] = T
+    for e in P["conditioner_config"]["params"]["emb_models"]:
+        if e["target"].endswith("VideoPredictionEmbedderWithEncoder"):
+            e["params"]["encoder_config"]["params"]["ddconfig"]["ch"] = 64
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as fh:
+        yaml.safe_dump(y, fh)
+    model = create_model(fh.name)
+    synth.fill_module_(model, seed=6)
+    emb = {type(e).__name__: (i, e) for i, e in enumerate(model.conditioner.embedders)}
+    di, depth = emb["DepthEmbedder"]
+    depth.load_state_dict(synth.damp_residual_tails({k: v.clone().float() for k, v in depth.state_dict().items()}, 0.25))
+    sd = {k: v.clone().float() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    model.sampler.device = dev
+    max_scale = P["sampler_config"]["params"]["guider_config"]["params"]["max_scale"]
+    assert max_scale == 2.0 and model.en_and_decode_n_samples_a_time == 1
+
+    g = torch.Generator().manual_seed(21)
+    video = (torch.rand((1, 3, T, HW, HW), generator=g) * 2 - 1)
+    # ---- conditioner (v02.py:104-113)
+    torch.manual_seed(77)                                       # add_custom_cond draws the cond_aug noise on the device generator
+    batch = model.add_custom_cond({"video": video.to(dev), "elevation": torch.tensor([10.0], device=dev)}, infer=True)
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames", "cond_frames_without_noise"])
+    h = HW // 8
+    assert c["crossattn"].shape == (1, 1, 1024) and c["vector"].shape == (1, 512) and c["concat"].shape == (T, 13, h, h)
+    cf = batch["cond_frames"].float().cpu()
+    pre = lambda i: f"conditioner.embedders.{i}."
+    sub = lambda i: {k[len(pre(i)):]: v for k, v in sd.items() if k.startswith(pre(i))}
+    ci, clip = emb["FrozenOpenCLIPImagePredictionEmbedder"]
+    with torch.no_grad():
+        ref_ctx = O.openclip_image_embedder(sub(ci), batch["cond_frames_without_noise"].float().cpu(), clip.open_clip.model.cfg["heads"])
+        ref_vec = torch.cat([O.sinusoid(torch.tensor([10.0]), 256), O.sinusoid(torch.tensor([0.02]).half().float(), 256)], 1)
+        vi, _ = emb["VideoPredictionEmbedderWithEncoder"]
+        edd = P["first_stage_config"]["params"]["ddconfig"]
+        ref_lat_c = O.vae_encode(sub(vi), edd, cf, None, scale_factor=1.0, prefix="encoder.")           # mode only, embedder scale 1
+        ref_depth = O.depth_embedder(sub(di), cf, prefix="model.model.")
+    r = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    cosf = lambda a, b: torch.nn.functional.cosine_similarity(a.float().cpu().flatten(), b.flatten(), dim=0).item()
+    print(f"stage2 e2e conditioner: crossattn rel {r(c['crossattn'], ref_ctx):.4f}  vector rel {r(c['vector'], ref_vec):.5f}  "
+          f"concat latents rel {r(c['concat'][:, 9:], ref_lat_c):.4f}  depth |diff| {(c['concat'][:, :9].float().cpu() - ref_depth).abs().max():.4f}")
+    assert r(c["crossattn"], ref_ctx) < 3e-2 and r(c["vector"], ref_vec) < 2e-3 and r(c["concat"][:, 9:], ref_lat_c) < 4e-2
+    assert (c["concat"][:, :9].float().cpu() - ref_depth).abs().max() < 1e-1 and cosf(c["concat"][:, :9], ref_depth) > 0.999
+    assert float(uc["concat"].abs().max()) == 0.0 and float(uc["crossattn"].abs().max()) == 0.0 and torch.equal(uc["vector"], c["vector"])
+
+    # ---- per-frame encode + refine + decode (v02.py:96-135), same noise draws on both sides
+    enc_noise = torch.randn((T, 4, h, h), generator=g)
+    init = torch.randn((T, 4, h, h), generator=g)
+    lat = pipelines.stage2_refine(model, video[0].to(dev), c, uc, init_noise=init, encode_noise=enc_noise, decode=False)
+    img = model.decode_first_stage(lat)
+    assert img.shape == (T, 3, HW, HW)
+    ucfg = dict(model.model.diffusion_model.cfg)
+    dd = P["first_stage_config"]["params"]["ddconfig"]
+    cpu = lambda d: {k: v.float().cpu() for k, v in d.items()}
+    with torch.no_grad():
+        z_ref = torch.cat([O.vae_encode(sd, dd, video[0, :, t].unsqueeze(0), enc_noise[t:t + 1]) for t in range(T)], 0)
+        # the oracle chain continues from the PRODUCT's conditioning: the conditioner was compared above, and the refine
+        # loop is judged on identical c / uc (its own error budget, not the depth network's)
+        lat_ref = O.v02_refine(sd, ucfg, z_ref, init, cpu(c), cpu(uc), T, steps, max_scale)
+        img_ref = O.vae_decode(sd, dd, lat_ref)
+    a0 = pipelines.v02_alpha(0, steps)
+    assert abs(a0 - 1.0) < 1e-12 and abs(pipelines.v02_alpha(1, steps) - math.pow(0.5 * (1 + math.cos(1 / steps)), 40.0)) < 1e-12
+    lat_rel, img_rel = r(lat, lat_ref), r(img, img_ref)
+    print(f"stage2 e2e: latents rel {lat_rel:.4f} cos {cosf(lat, lat_ref):.6f}  image rel {img_rel:.4f} cos {cosf(img, img_ref):.6f}")
+    assert lat_rel < 6e-2 and cosf(lat, lat_ref) > 0.999 and img_rel < 8e-2 and cosf(img, img_ref) > 0.998

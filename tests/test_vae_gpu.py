@@ -135,3 +135,34 @@ def test_video_decoder_matches_reference_golden(dev, name):
     eng.first_stage_model, eng.scale_factor, eng.en_and_decode_n_samples_a_time = ae, 0.5, fx["T"]
     out2 = eng.decode_first_stage(fx["z"].to(dev) * 0.5).float().cpu()          # chunk of T frames -> timesteps=T
     assert ((out2 - ref).abs().max() / ref.abs().max()).item() < 4e-2
+
+
+def test_autoencoding_engine_encode_matches_reference_golden(dev):
+    """AutoencodingEngine.encode (models/autoencoder.py:196-209; no quant convs): raw moments, the sampled posterior with the
+    reference's own CPU noise draw, the default CPU-generator draw, and `sample: false` (the mode)."""
+    from hi3d_hip import synth
+    from sgm.models.autoencoder import AutoencodingEngine
+    fx = torch.load(os.path.join(GOLD, "engine_enc_tiny.pt"), weights_only=False)
+    dd = fx["ddconfig"]
+
+    def build(reg_params=None):
+        ae = AutoencodingEngine(
+            encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
+            decoder_config={"target": "sgm.modules.diffusionmodules.model.Decoder", "params": dd},
+            regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer", "params": reg_params})
+        assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == fx["shapes"]
+        synth.fill_module_(ae, fx["weight_seed"], prefix=fx["key_prefix"])
+        return ae.to(dev)
+    ae = build()
+    x = fx["x"].to(dev)
+    mom, log = ae.encode(x, unregularized=True)
+    assert log == {} and mom.shape == fx["moments"].shape
+    r = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    z = ae.encode(x, noise=fx["sample_noise"])
+    print(f"engine encode: moments rel {r(mom, fx['moments']):.4f}  sample rel {r(z, fx['z_sampled']):.4f}")
+    assert r(mom, fx["moments"]) < 4e-2 and r(z, fx["z_sampled"]) < 4e-2
+    torch.manual_seed(4321)                          # the seed the reference run drew its posterior noise with
+    z2, log2 = ae.encode(x, return_reg_log=True)
+    assert torch.equal(z2, z) and isinstance(log2, dict)
+    zm = build({"sample": False}).encode(x)
+    assert r(zm, fx["moments"][:, :dd["z_channels"]]) < 4e-2
