@@ -44,7 +44,7 @@ def build_torch_ops(force=False, verbose=True):
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            f"-I{tp}/include", f"-I{tp}/include/torch/csrc/api/include", "-I/opt/rocm/include", TORCH_SRC, "-o", TORCH_LIB,
-           f"-L{tp}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", f"-L{os.path.dirname(LIB)}", "-lhi3d_hip", "-Wl,-rpath,$ORIGIN"]
+           f"-L{tp}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{os.path.dirname(LIB)}", "-lhi3d_hip", "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("torch_ops.cpp failed to build:\n" + r.stdout.decode()[-4000:])

@@ -9,8 +9,8 @@
 // the operands' device, and a non-zero status of the C ABI is raised with hi3d_last_error().  There is no CPU or ATen
 // fallback: the ops are registered for the CUDA (= HIP) dispatch key only.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm tensors carry DeviceType::CUDA
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include "../../include/hi3d_hip.h"
@@ -19,7 +19,7 @@ namespace {
 
 using at::Tensor;
 
-void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (rc=", rc, "): ", hi3d_last_error()); }
 
@@ -40,7 +40,7 @@ Tensor self_attention(const Tensor& qkv, int64_t B, int64_t S, int64_t H, double
   const int64_t C = H * 64;
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * S && qkv.size(1) == 3 * C, "hi3d::self_attention: qkv must be [B*S, 3*H*64]");
   TORCH_CHECK(scale > 0.0, "hi3d::self_attention: scale must be > 0");
-  const c10::hip::HIPGuard guard(qkv.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
   const int64_t S_pad = (S + 63) / 64 * 64, ld = qkv.stride(0);
   Tensor vt = at::empty({B, H, 64, S_pad}, qkv.options());
   Tensor out = at::empty({B * S, C}, qkv.options());
@@ -59,7 +59,7 @@ Tensor attn_d64(const Tensor& q, const Tensor& k, const Tensor& v, int64_t B, in
   TORCH_CHECK(q.size(1) >= H * 64 && k.size(1) >= H * 64 && v.size(1) >= H * 64, "hi3d::attn_d64: fewer than H*64 columns");
   TORCH_CHECK(q.device() == k.device() && q.device() == v.device(), "hi3d::attn_d64: operands on different devices");
   TORCH_CHECK(scale > 0.0, "hi3d::attn_d64: scale must be > 0");
-  const c10::hip::HIPGuard guard(q.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
   const int64_t S_pad = (S_kv + 63) / 64 * 64;
   Tensor vt = at::empty({B, H, 64, S_pad}, q.options());
   Tensor out = at::empty({B * S_q, H * 64}, q.options());
@@ -74,7 +74,7 @@ Tensor attn_temporal(const Tensor& qkv, int64_t B, int64_t T, int64_t S, int64_t
   want_bf16_rows(qkv, "hi3d::attn_temporal qkv");
   const int64_t C = H * 64;
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * T * S && qkv.size(1) == 3 * C, "hi3d::attn_temporal: qkv must be [B*T*S, 3*H*64]");
-  const c10::hip::HIPGuard guard(qkv.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
   Tensor out = at::empty({B * T * S, C}, qkv.options());
   const char* base = (const char*)qkv.data_ptr();
   check_rc(hi3d_attn_temporal_d64(base, base + C * 2, base + 4 * C, out.data_ptr(), (int)B, (int)T, (int)S, (int)H, (int)qkv.stride(0), (int)C,
@@ -87,7 +87,7 @@ Tensor groupnorm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta, 
   want_bf16_rows(x, "hi3d::groupnorm_silu x");
   TORCH_CHECK(x.is_contiguous() && x.numel() == inst * P * C, "hi3d::groupnorm_silu: x must be contiguous [inst*P, C]");
   want_f32(gamma, "hi3d::groupnorm_silu gamma", C); want_f32(beta, "hi3d::groupnorm_silu beta", C);
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   Tensor ws = at::empty({hi3d_gn_workspace_floats((int)inst, (int)P, (int)C)}, x.options().dtype(at::kFloat));
   check_rc(hi3d_groupnorm_silu(x.data_ptr(), y.data_ptr(), gamma.data_ptr<float>(), beta.data_ptr<float>(), ws.data_ptr<float>(), (int)inst, (int)P,
@@ -101,7 +101,7 @@ Tensor layernorm(const Tensor& x, const Tensor& gamma, const Tensor& beta, doubl
   TORCH_CHECK(x.is_contiguous(), "hi3d::layernorm: contiguous x required");
   const int64_t C = x.size(-1), R = x.numel() / C;
   want_f32(gamma, "hi3d::layernorm gamma", C); want_f32(beta, "hi3d::layernorm beta", C);
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   check_rc(hi3d_layernorm(x.data_ptr(), y.data_ptr(), nullptr, gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr, 1, (int)R, (int)C, (float)eps,
                           stream_of(x)), "hi3d_layernorm");
@@ -115,7 +115,7 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   if (bias.has_value()) want_f32(*bias, "hi3d::linear bias", N);
   if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::linear residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == N, "hi3d::linear: residual must be [M, N]"); }
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, N}, x.options());
   hi3d_gemm_desc d = {};
   d.A = x.data_ptr(); d.W = w.data_ptr(); d.bias = (const float*)opt_ptr(bias); d.R1 = opt_ptr(residual); d.out = out.data_ptr();
@@ -137,7 +137,7 @@ Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bi
   const int64_t Ho = up2x ? 2 * H : (stride == 2 ? (H + 1) / 2 : H), Wo = up2x ? 2 * W : (stride == 2 ? (W + 1) / 2 : W), M = N * Ho * Wo;
   if (bias.has_value()) want_f32(*bias, "hi3d::conv3x3 bias", Cout);
   if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::conv3x3 residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == Cout, "hi3d::conv3x3: residual must be [M, Cout]"); }
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, Cout}, x.options());
   hi3d_gemm_desc d = {};
   d.A = x.data_ptr(); d.W = w.data_ptr(); d.bias = (const float*)opt_ptr(bias); d.R1 = opt_ptr(residual); d.out = out.data_ptr();
@@ -159,7 +159,7 @@ Tensor ffn_geglu(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tens
               "hi3d::ffn_geglu: w1 [8C, C], w2 [C, 4C] required");
   want_f32(b1, "hi3d::ffn_geglu b1", 8 * C); want_f32(b2, "hi3d::ffn_geglu b2", C);
   if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::ffn_geglu residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == C, "hi3d::ffn_geglu: residual must be [M, C]"); }
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, C}, x.options());
   const int ldr = residual.has_value() ? (int)residual->stride(0) : 0;
   int rc = hi3d_ffn_geglu(x.data_ptr(), w1.data_ptr(), b1.data_ptr<float>(), w2.data_ptr(), b2.data_ptr<float>(), opt_ptr(residual), nullptr, nullptr,

@@ -1,0 +1,141 @@
+"""Timing-perturbation stress of a gfx950 kernel at the ISA level.
+
+Background: the round-2 build of the flash-attention kernel returned wrong rows in a few launches out of a
+thousand.  Every source-level experiment moved the failure around, because any source change re-schedules the whole kernel.
+What finally characterised it was patching the DEVICE ASSEMBLY of the failing build: idle wait states inserted after one
+class of instruction, everything else bit-identical.  A kernel without a latent timing dependence is indifferent to such
+patches (wait states cannot change the result of a correct program); the round-2 build broke in EVERY launch as soon as
+16 idle wait states separated two MFMAs that are adjacent in its instruction stream, with two waves on the SIMD.
+
+This module turns that into a reusable check:  device assembly of a .hip file (hipcc -S), a set of perturbation patches
+applied to ONE kernel symbol, re-assembly into code objects (clang -x assembler, ld.lld) and launch through the HIP module
+API on the HIP runtime torch is linked to.  tests/test_kernels_gpu.py runs the shipped attention kernels under every patch
+and requires bit-identical output.
+"""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def device_asm(hip_file, include_dirs=()):
+    """gfx950 device assembly of a .hip translation unit (list of lines)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-S",
+               "--cuda-device-only", "-o", out, hip_file] + [f"-I{i}" for i in include_dirs]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return open(out).read().split("\n")
+
+
+def opcode(line):
+    m = re.match(r"\s+([a-z_0-9]+)", line)
+    return m.group(1) if m else None
+
+
+def kernel_span(lines, symbol):
+    a = next(i for i, l in enumerate(lines) if l.startswith(symbol + ":"))
+    b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
+    return a, b
+
+
+def insert(lines, symbol, when, extra, before=False):
+    """`extra` (asm lines) after -- or before -- every instruction of kernel `symbol` for which when(opcode, line)."""
+    a, b = kernel_span(lines, symbol)
+    out, n = [], 0
+    for i, l in enumerate(lines):
+        hit = a <= i <= b and opcode(l) is not None and when(opcode(l), l)
+        if hit and before:
+            out += extra
+        out.append(l)
+        if hit and not before:
+            out += extra
+        n += hit
+    return out, n
+
+
+NOP16 = ["\ts_nop 15"]
+is_mfma = lambda op, l: op.startswith("v_mfma")          # noqa: E731
+PATCHES = {
+    # name: (predicate, inserted lines, before?)
+    "mfma_then_32_idle": (is_mfma, NOP16 * 2, False),                       # what broke the round-2 build in every launch
+    "16_idle_then_mfma": (is_mfma, NOP16, True),
+    "lds_drained_before_mfma": (is_mfma, ["\ts_waitcnt lgkmcnt(0)"], True),
+    "packed_fp32_then_4_idle": (lambda op, l: op.startswith("v_pk_"), ["\ts_nop 3"], False),
+    "exp_then_8_idle": (lambda op, l: op.startswith("v_exp"), ["\ts_nop 7"], False),
+    "every_valu_then_2_idle": (lambda op, l: op.startswith("v_") and not op.startswith("v_mfma"), ["\ts_nop 1"], False),
+    "valu_noop_after_mfma": (is_mfma, ["\tv_nop"], False),                   # adjacent MFMAs split by one VALU instruction
+    "barrier_then_64_idle": (lambda op, l: op == "s_barrier", NOP16 * 4, False),
+    "sleep_after_mfma": (is_mfma, ["\ts_sleep 2"], False),
+}
+
+
+def assemble(lines, path):
+    """asm lines -> loadable code object at `path` (.hsaco)."""
+    s_path = path + ".s"
+    with open(s_path, "w") as fh:
+        fh.write("\n".join(lines))
+    subprocess.run([f"{LLVM}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", path + ".o"], check=True)
+    subprocess.run([f"{LLVM}/ld.lld", "-shared", path + ".o", "-o", path], check=True)
+    os.remove(path + ".o")
+    os.remove(s_path)
+    return path
+
+
+class Module:
+    """A code object loaded through hipModuleLoad on torch's HIP runtime; launch(kernel, grid, block, packed kernarg bytes)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import torch
+            h = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            h.hipModuleLoad.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
+            h.hipModuleGetFunction.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_char_p]
+            h.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]
+            h.hipModuleUnload.argtypes = [C.c_void_p]
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self, path):
+        self.mod = C.c_void_p()
+        rc = self.hip().hipModuleLoad(C.byref(self.mod), path.encode())
+        if rc:
+            raise RuntimeError(f"hipModuleLoad({path}) -> {rc}")
+        self.fns = {}
+
+    def launch(self, symbol, grid, block, kernarg, stream):
+        fn = self.fns.get(symbol)
+        if fn is None:
+            fn = C.c_void_p()
+            rc = self.hip().hipModuleGetFunction(C.byref(fn), self.mod, symbol.encode())
+            if rc:
+                raise RuntimeError(f"hipModuleGetFunction({symbol}) -> {rc}")
+            self.fns[symbol] = fn
+        kernarg += b"\0" * (-len(kernarg) % 8)
+        buf = C.create_string_buffer(kernarg, len(kernarg))
+        size = C.c_size_t(len(kernarg))
+        extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p).value, 2, C.cast(C.pointer(size), C.c_void_p).value, 3)
+        rc = self.hip().hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, stream, None, extra)
+        if rc:
+            raise RuntimeError(f"hipModuleLaunchKernel({symbol}) -> {rc}")
+
+    def close(self):
+        self.hip().hipModuleUnload(self.mod)
+
+
+# ---- the attention kernel of csrc/attention.hip ---------------------------------------------------------------------
+ATTN_SYMBOL = {True: "_ZN12_GLOBAL__N_115attn_d64_kernelILb1EEEvNS_10AttnParamsE",      # q pre-scaled
+               False: "_ZN12_GLOBAL__N_115attn_d64_kernelILb0EEEvNS_10AttnParamsE"}
+
+
+def attn_kernarg(q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, scale):
+    """struct AttnParams of csrc/attention.hip (4 pointers, 10 ints incl. force_exact = 0, scale * log2 e)."""
+    nqt = (S_q + 255) // 256
+    return struct.pack("<4Q10if", q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, nqt, 0, scale * 1.4426950408889634), nqt * H * B

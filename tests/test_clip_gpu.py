@@ -126,18 +126,25 @@ def test_aes_embedder_end_to_end(dev):
 def test_resample_image_matches_oracle(dev, kind, hw):
     """hi3d_resample_axis (two banded passes + fused CLIP affine) vs the oracle's restatement of the reference's resizes:
     kornia.geometry.resize(bicubic, align_corners, antialias) (modules.py:619-628) / F.interpolate(bilinear) + crop
-    (vtdm/encoders.py:80-83).  fp32 throughout: 1e-5 absolute on O(1) values."""
+    (vtdm/encoders.py:80-83).  fp32 throughout, the 70-odd taps of a pixel summed in another order than the reference's
+    blur-then-interpolate: 5e-5 absolute on values up to 2.6."""
     from oracle import hi3d_oracle as O
     from hi3d_hip import ops
     img = torch.rand((2, 3) + hw, generator=torch.Generator().manual_seed(7)) * 2 - 1
     mean, std = torch.tensor(O.CLIP_MEAN), torch.tensor(O.CLIP_STD)
+    # reference in float64: aten computes the source coordinate o * (in - 1) / (out - 1) in the tensor's precision, which in
+    # fp32 at 1024 pixels is worth 6e-5 of a pixel -- the fp32 reference run disagrees with ITSELF in fp64 by that much; the
+    # tap tables here are built in fp64, so the kernel is compared with the exact arithmetic (and loosely with the fp32 run)
     if kind == "clip224":
-        ref = O.kornia_resize(img, (224, 224))
+        ref = O.kornia_resize(img.double(), (224, 224))
+        ref32 = O.kornia_resize(img, (224, 224))
     else:
-        ref = F.interpolate(img, [224, 384], mode="bilinear")[:, :, :, 80:304]
-    ref = ((ref + 1) * 0.5 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+        ref = F.interpolate(img.double(), [224, 384], mode="bilinear")[:, :, :, 80:304]
+        ref32 = F.interpolate(img, [224, 384], mode="bilinear")[:, :, :, 80:304]
+    norm = lambda t: ((t + 1) * 0.5 - mean.view(1, 3, 1, 1).to(t.dtype)) / std.view(1, 3, 1, 1).to(t.dtype)
+    ref, ref32 = norm(ref).float(), norm(ref32)
     out = ops.resample_image(img.to(dev), kind, scale=(0.5 / std).to(dev), shift=((0.5 - mean) / std).to(dev))
     assert out.shape == ref.shape
-    assert (out.cpu() - ref).abs().max() < 1e-5
+    assert (out.cpu() - ref).abs().max() < 1e-5 and (out.cpu() - ref32).abs().max() < 3e-4
     plain = ops.resample_image(img.to(dev), kind)            # no affine
     assert (plain.cpu() * (0.5 / std).view(1, 3, 1, 1) + ((0.5 - mean) / std).view(1, 3, 1, 1) - ref).abs().max() < 1e-5

@@ -253,22 +253,70 @@ def test_attention_d64(dev, B, H, S):
     assert relerr(out, ref) < 2e-2     # P is rounded to bf16 before PV
 
 
-@pytest.mark.parametrize("B,H,S", [(16, 12, 577), (16, 12, 513), (8, 16, 257)])
-def test_attention_d64_ragged_repeatable(dev, B, H, S):
-    """Sequence lengths with a ragged last key tile (the ViT towers of the conditioner: 577 / 257 tokens), many blocks
-    per CU, 40 launches on fixed inputs: bitwise equal, and right.  (Round 2: one build of this kernel returned, in
-    1-3 of 30 such launches, 16 wrong query rows -- rows 48..63 of one wave, errors of order 1 -- only with a ragged
-    key tile, on several boxes; adding an unrelated kernel parameter made it vanish (0 of 236 launches).  No source-level
-    cause was found: profiles/r02e_diag_attn_ragged*.log, DESIGN 4b.  This test is the tripwire.)"""
+@pytest.mark.parametrize("force_exact", [False, True])
+@pytest.mark.parametrize("S", [1, 12, 48, 63, 65, 129, 257, 513, 577])
+def test_attention_d64_ragged_repeatable(dev, S, force_exact, monkeypatch):
+    """Sequence lengths with keys beyond S_kv in the last tile (the ViT towers of the conditioner run 577 / 257 tokens), many
+    blocks per CU, 1000 launches per length on fixed inputs: bitwise equal, and right -- with and without the debug switch
+    that sends every key tile through the exact pre-pass.  Round 2's build of this kernel returned 16 wrong query rows
+    (rows 48..63 of one wave, errors of order 1) in a few launches per thousand; the incident is closed in DESIGN 4c:
+    the peeled ragged-tile copy is gone (keys >= S_kv get -inf through the C operand of the score MFMA, one code path),
+    and the kernel is stress-tested at the ISA level (test_attention_isa_timing_stress below)."""
     from hi3d_hip import ops
+    if force_exact:
+        monkeypatch.setenv("HI3D_ATTN_FORCE_EXACT", "1")
+    H = 12
+    B = max(16, min(512, (2 * 256 * 4 + S - 1) // S))        # enough blocks for >= 2 per CU at every length
     C = H * 64
-    qkv = bf(rnd((B * S, 3 * C), 17, 1.5)).to(dev)
-    outs = [ops.self_attention_fused_qkv(qkv, B, S, H) for _ in range(40)]
-    bad = [i for i in range(1, 40) if not torch.equal(outs[i], outs[0])]
-    assert not bad, f"launches {bad} differ from the first"
+    qkv = bf(rnd((B * S, 3 * C), 17 + S, 1.5)).to(dev)
+    first = ops.self_attention_fused_qkv(qkv, B, S, H)
+    ring = [torch.empty_like(first) for _ in range(25)]
+    vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+    bad = 0
+    for rnd_ in range(40):                                   # 40 x 25 = 1000 launches
+        for o in ring:
+            ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, 64 ** -0.5, out=o)
+        bad += int(torch.stack([(o != first).any() for o in ring]).sum())
+    assert bad == 0, f"{bad} of 1000 launches differ from the first"
     q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * S, C)
-    assert relerr(outs[0], ref) < 2e-2
+    assert relerr(first, ref) < 2e-2
+
+
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_isa_timing_stress(dev, pre, tmp_path):
+    """The shipped attention kernels with idle wait states / waits / VALU no-ops patched into their DEVICE ASSEMBLY
+    (hi3d_hip.devtools.isa_stress: after every MFMA, before every MFMA, after every packed-fp32 / exp / VALU instruction,
+    adjacent MFMAs split, the barrier delayed ...), two blocks per CU: bit-identical to the library's own launch, in every
+    launch, at a full and at a ragged length.  Wait states cannot change what a correct program computes; the round-2 build
+    of this kernel failed EVERY launch under the first of these patches (gpurun_out -> profiles/r03a_asm_lab*.log)."""
+    import os
+    from hi3d_hip import ops
+    from hi3d_hip.devtools import isa_stress as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = I.device_asm(os.path.join(root, "hi3d-official_amd", "csrc", "attention.hip"))
+    sym = I.ATTN_SYMBOL[pre]
+    B, H = 16, 12
+    C = H * 64
+    st = torch.cuda.current_stream().cuda_stream
+    for name, (when, extra, before) in I.PATCHES.items():
+        pl, n = I.insert(lines, sym, when, extra, before)
+        assert n > 0, name
+        mod = I.Module(I.assemble(pl, str(tmp_path / (name + ".hsaco"))))
+        for S in (576, 577):
+            qkv = bf(rnd((B * S, 3 * C), 23, 1.5)).to(dev)
+            vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+            scale = 0.0 if pre else 0.125
+            ref = ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
+            outs = [torch.empty_like(ref) for _ in range(20)]
+            for o in outs:
+                arg, grid = I.attn_kernarg(qkv.data_ptr(), qkv[:, C:].data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, S, S, 3 * C, 3 * C,
+                                           vt.shape[-1], C, scale)
+                mod.launch(sym, grid, 256, arg, st)
+            torch.cuda.synchronize()
+            nbad = sum(int(not torch.equal(o, ref)) for o in outs)
+            assert nbad == 0, f"patch {name}, S={S}: {nbad} of 20 launches differ from the unpatched kernel"
+        mod.close()
 
 
 def test_attention_d64_online_softmax_rescale(dev):

@@ -77,6 +77,41 @@ def main():
                         "      { float* dp = (float*)(p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + p.H * 64) + (h * 2 + hi) * 6;\n"
                         "        for (int i = 0; i < 6; ++i) dp[i] = dbg[qb][i]; }")
     variants["n_dump"] = (dump, [])
+    # second dump: l at the entry of the peeled tile, d, alpha, l after the pre-pass, m after, row sum
+    d2 = must_replace(nops, "  float m_run[QB], l_run[QB];", "  float m_run[QB], l_run[QB];\n  float dbg[QB][6] = {};")
+    d2 = must_replace(d2, "          const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);",
+                      "          const float alpha = (j == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);\n"
+                      "          if (ragged) { dbg[qb][0] = l_run[qb]; dbg[qb][1] = d; dbg[qb][2] = alpha; }")
+    d2 = must_replace(d2, "          l_run[qb] *= alpha;", "          l_run[qb] *= alpha;\n          if (ragged) { dbg[qb][3] = l_run[qb]; dbg[qb][4] = m_run[qb]; }")
+    d2 = must_replace(d2, "    for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum[qb];",
+                      "    for (int qb = 0; qb < QB; ++qb) { if (ragged) dbg[qb][5] = psum[qb]; l_run[qb] += psum[qb]; }")
+    d2 = must_replace(d2, "      unsigned short* op = p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + h * 64;",
+                      "      unsigned short* op = p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + h * 64;\n"
+                      "      { float* dp = (float*)(p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + p.H * 64) + (h * 2 + hi) * 6;\n"
+                      "        for (int i = 0; i < 6; ++i) dp[i] = dbg[qb][i]; }")
+    variants["n2_dump"] = (d2, [])
+    # where does the state go wrong: in the loop over the full tiles (with the LDS-DMA of the ragged tile in flight during
+    # the last of them), or inside the peeled tile?
+    variants["n_skiplast"] = (must_replace(nops, "  if (nfull < ntile) tile(nfull, std::true_type{});", "  /* peeled tile skipped */"), [])
+    late = must_replace(nops, "    if (j + 1 < ntile) issue(j + 1, (j & 1) ^ 1);",
+                        "    if (j + 1 < (ragged ? ntile : nfull)) issue(j + 1, (j & 1) ^ 1);")
+    late = must_replace(late, "  if (nfull < ntile) tile(nfull, std::true_type{});",
+                        "  if (nfull < ntile) { if (nfull > 0) { __syncthreads(); issue(nfull, nfull & 1); } tile(nfull, std::true_type{}); }")
+    variants["n_lateissue"] = (late, [])
+    # third dump: history of l over the last three FULL tiles + at the entry of the peeled one (same binary runs S = 576, too)
+    d3 = must_replace(nops, "  float m_run[QB], l_run[QB];", "  float m_run[QB], l_run[QB];\n  float dbg[QB][6] = {};")
+    d3 = must_replace(d3, "    for (int qb = 0; qb < QB; ++qb) l_run[qb] += psum[qb];",
+                      "    for (int qb = 0; qb < QB; ++qb) {\n"
+                      "      if (ragged) { dbg[qb][3] = l_run[qb]; dbg[qb][5] = psum[qb]; }\n"
+                      "      l_run[qb] += psum[qb];\n"
+                      "      if (!ragged) { if (j == nfull - 3) dbg[qb][0] = l_run[qb]; if (j == nfull - 2) dbg[qb][1] = l_run[qb];\n"
+                      "                     if (j == nfull - 1) { dbg[qb][2] = l_run[qb]; dbg[qb][4] = psum[qb]; } }\n"
+                      "    }")
+    d3 = must_replace(d3, "      unsigned short* op = p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + h * 64;",
+                      "      unsigned short* op = p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + h * 64;\n"
+                      "      { float* dp = (float*)(p.out + ((long)b * p.Sq + qrow[qb]) * p.ldo + p.H * 64) + (h * 2 + hi) * 6;\n"
+                      "        for (int i = 0; i < 6; ++i) dp[i] = dbg[qb][i]; }")
+    variants["n3_dump"] = (d3, [])
     only = sys.argv[1:]
     procs = []
     for name, (src, extra) in variants.items():

@@ -72,13 +72,12 @@ def forensics(qkv, B, S, H, good, bad, scale):
             print(f"        differing d columns: {nz.nonzero().flatten().tolist()}")
 
 
-def show_dump(first, bad, B, S, H):
+def show_dump(first, bad, B, S, H, names=("m_before", "own_max", "tile_max", "l_before", "psum", "l_after")):
     """n_dump variant: columns H*64.. of every output row hold, per (head, half-wave), six floats of the peeled tile's softmax
     state: m before, own max, tile max, l before, row sum, l after."""
     Cc = H * 64
     d = (bad[:, :Cc].float() - first[:, :Cc].float()).abs()
     rows = d.amax(dim=1).nonzero().flatten().tolist()
-    names = ("m_before", "own_max", "tile_max", "l_before", "psum", "l_after")
     shown = 0
     for r in rows:
         heads = d[r].view(H, 64).amax(dim=1).nonzero().flatten().tolist()
@@ -141,7 +140,8 @@ def run(name, launches, B, H, S, scale):
                     shown += 1
                     print(f"  launch {done + i}: {rws.numel()} rows differ, max |diff| {float(d.max()):.3e}")
                     if dump:
-                        show_dump(first, ring[i], B, S, H)
+                        show_dump(first, ring[i], B, S, H, *({"n_dump": (), "n3_dump": (("l_tile-3", "l_tile-2", "l_tile-1", "l_peel_entry", "psum_tile-1", "psum_peel"),)}.get(
+                                      name, (("l_entry", "d", "alpha", "l_scaled", "m_after", "psum"),))))
                     else:
                         forensics(qkv, B, S, H, first[:, :Cc], ring[i][:, :Cc], scale if scale else 1.0 / 1.4426950408889634)
         done += n
@@ -188,7 +188,7 @@ def main():
     names = [a for a in args if not a.isdigit()] or sorted(os.listdir(LAB))
     print(torch.cuda.get_device_name(0))
     for name in names:
-        for (B, H, S) in ((16, 12, 577), (16, 12, 513)):
+        for (B, H, S) in ((16, 12, 577), (16, 12, 513)) + (((16, 12, 576),) if name == "n3_dump" else ()):
             run(name, launches, B, H, S, 0.125)
     tn = [n for n in ("r2ship", "unified") if n in names]
     if len(tn) == 2:
