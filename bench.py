@@ -66,9 +66,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["s1", "s2", "vae"], default="s2")
     ap.add_argument("--views", type=int, default=16)
-    ap.add_argument("--attn", choices=["bf16", "fp8qk"], default="bf16",
-                    help="fp8qk: BASELINE config 5 -- spatial attention scores on the fp8 (e4m3, MX-scaled) matrix path, "
-                         "P V and everything else bf16; reported as dtype fp8-qk/bf16 (reduced precision, own tolerance)")
+    ap.add_argument("--attn", choices=["bf16", "fp8qk", "fp8"], default="bf16",
+                    help="BASELINE config 5 (fp8 MFMA attention + bf16 conv; reduced precision, own tolerances): fp8qk = the score "
+                         "product of the spatial attention on the e4m3 / e8m0-scaled matrix path, P V bf16; fp8 = both products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
@@ -145,7 +145,8 @@ def run_legs(a, rank, world, dev):
     legs = {}
     plan = (("s1_16views_512", dict(stage=1, T=16, attn="bf16")),        # BASELINE config 2
             ("s2_32views_1024", dict(stage=2, T=32, attn="bf16")),       # config 4
-            ("s2_16views_fp8qk", dict(stage=2, T=16, attn="fp8qk")))     # config 5 (fp8 score product, own tolerance)
+            ("s2_16views_fp8qk", dict(stage=2, T=16, attn="fp8qk")),     # config 5, score product only (own tolerance)
+            ("s2_16views_fp8", dict(stage=2, T=16, attn="fp8")))         # config 5, both attention products on fp8
     for name, kw in plan:
         gc.collect(); torch.cuda.empty_cache()
         try:
@@ -176,6 +177,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
     from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
     os.environ["HI3D_ATTN_FP8QK"] = "1" if attn == "fp8qk" else "0"       # read when the runtime is built
+    os.environ["HI3D_ATTN_FP8"] = "1" if attn == "fp8" else "0"
     lat = 64 if stage == 1 else 128
     cfg = unet_cfg(stage)
     t0 = time.time()
@@ -251,7 +253,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                   else f"denoise-steps/sec (UNet fwd) at {T} views x {lat * 8}^2",
         "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if attn == "bf16" else "fp8-qk/bf16", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp8qk": "fp8-qk/bf16", "fp8": "fp8-attention/bf16"}[attn], "data": "synthetic",
         "config": {"workload": f"Hi3D stage-{stage} VideoUNet sampler step, {T} views @ {lat * 8}x{lat * 8} "
                                f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
                                "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
@@ -287,7 +289,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         # dominant kernel: the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm_bf16_kernel, all A-gather modes)
         g = [d for f, d in summ.items() if f.startswith("gemm_")]   # (the fused feed-forward kernel is listed on its own line)
         g_ms, g_fl, g_n = sum(d["ms"] for d in g), sum(d["flops"] for d in g), sum(d["launches"] for d in g)
-        at = summ.get("attn_d64", summ.get("attn_d64_fp8qk", dict(ms=0.0, flops=0.0, launches=1)))
+        at = summ.get("attn_d64", summ.get("attn_d64_fp8qk", summ.get("attn_d64_fp8", dict(ms=0.0, flops=0.0, launches=1))))
         dom_is_gemm = g_ms >= at["ms"]
         k_ms, k_fl, k_n = (g_ms, g_fl, g_n) if dom_is_gemm else (at["ms"], at["flops"], at["launches"])
         ach = k_fl / (k_ms * 1e-3) / 1e12
@@ -306,7 +308,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                            "timing": f"HIP events around every launch over the {steps} steps after the timed region "
                                      "(the timed steps are graph replays)"}
         out["kernels_ms_per_step"] = {f: round(d["ms"] / steps, 3) for f, d in fams}
-        for fam in ("attn_d64", "attn_d64_fp8qk"):
+        for fam in ("attn_d64", "attn_d64_fp8qk", "attn_d64_fp8"):
             if fam not in summ:
                 continue
             d = summ[fam]

@@ -188,6 +188,30 @@ def self_attention_fused_qkv_fp8qk(qkv, B, S, H):
     return out
 
 
+def self_attention_fused_qkv_fp8(qkv, B, S, H):
+    """Both attention products on the fp8 matrix path (the full form of BASELINE config 5): q | k quantised as in
+    self_attention_fused_qkv_fp8qk, v quantised to e4m3 V^T tiles (one e8m0 exponent per d row and 64-key tile), P converted
+    to e4m3 in registers; one MFMA per (32 x 32) block and key tile for each product.  qkv: [B*S, 3*H*64] bf16, q carrying
+    Q_PRESCALE.  Reduced precision: own tolerance."""
+    C = H * 64
+    assert qkv.shape == (B * S, 3 * C) and qkv.is_contiguous()
+    _chk_dev(qkv)
+    ws = torch.empty(_lib.hi3d_attn_fp8_workspace_bytes(B, H, S), device=qkv.device, dtype=torch.uint8)
+    ws_v = torch.empty(_lib.hi3d_attn_fp8_v_workspace_bytes(B, H, S), device=qkv.device, dtype=torch.uint8)
+    out = torch.empty((B * S, C), device=qkv.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_attn_quant_qk(_p(qkv), _p(ws), B, H, S, 3 * C, _stream()), "hi3d_attn_quant_qk")
+    _l.check(_lib.hi3d_attn_quant_v(_p(qkv[:, 2 * C:]), _p(ws_v), B, H, S, 3 * C, _stream()), "hi3d_attn_quant_v")
+    if prof:
+        prof.end("quant_qkv", 0.0, 2.0 * 3 * B * S * C + 3 * B * S * (C + 2 * H), t0)
+        t0 = prof.begin()
+    _l.check(_lib.hi3d_attn_d64_fp8(_p(ws), _p(ws_v), _p(out), B, H, S, C, _stream()), "hi3d_attn_d64_fp8")
+    if prof:
+        prof.end("attn_d64_fp8", 4.0 * B * H * S * S * 64, B * H * 64.0 * (1 * S + 1 * S + 1 * S + 2 * S), t0)
+    return out
+
+
 def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
     """qkv: [(B*T*S), 3*H*64] bf16 in frame-major (b t s) row order."""
     C = H * 64

@@ -83,6 +83,8 @@ class UNetRuntime:
         # HI3D_ATTN_FP8QK=1: spatial attention scores on the fp8 matrix path (BASELINE config 5; reduced precision,
         # own tolerance) instead of bf16
         self.attn_fp8qk = os.environ.get("HI3D_ATTN_FP8QK", "0") == "1"
+        # HI3D_ATTN_FP8=1: both products (Q K^T and P V) on the fp8 matrix path; looser stated tolerance
+        self.attn_fp8 = os.environ.get("HI3D_ATTN_FP8", "0") == "1"
         self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
         self._pos_cache = {}
         self.steppers = {}      # (T, H, W) -> hi3d_hip.fused_step.FusedStepper
@@ -314,7 +316,8 @@ class UNetRuntime:
         # --- spatial block (attention.py:551-572)
         n = ops.layernorm(h, W[sp_ + ".norm1.g"], W[sp_ + ".norm1.b"], M, C)
         qkv = ops.gemm(n, W[sp_ + ".qkv.w"], M=M, N=3 * C, K=C)
-        a = ops.self_attention_fused_qkv_fp8qk(qkv, F_, S, Hh) if self.attn_fp8qk else \
+        a = ops.self_attention_fused_qkv_fp8(qkv, F_, S, Hh) if self.attn_fp8 else \
+            ops.self_attention_fused_qkv_fp8qk(qkv, F_, S, Hh) if self.attn_fp8qk else \
             ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
         h = ops.gemm(a, W[sp_ + ".o.w"], M=M, N=C, K=C, bias=W[sp_ + ".o.b"], R1=h,
                      rowvec=cond[sp_], rows_per_group=S)                    # + attn1 + attn2 (one token)

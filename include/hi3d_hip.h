@@ -140,6 +140,17 @@ int hi3d_attn_quant_qk(const void* qkv, void* ws, int32_t B, int32_t H, int32_t 
 int hi3d_attn_d64_fp8qk(const void* ws, const void* vt, void* out, int32_t B, int32_t H, int32_t S,
                         int32_t ld_vt, int32_t ldo, void* stream);
 
+/* The same attention with BOTH products on the fp8 matrix path (the full form of BASELINE.json config 5): P is converted to
+ * e4m3 in registers (constant scale 2^-3), V^T is quantised once per call by hi3d_attn_quant_v into e4m3 tiles
+ * [b][h][key tile][64 d][64] with one e8m0 exponent per (d, tile), keys in the order the P registers leave the score
+ * product in; O^T += V^T P^T is then ONE v_mfma_scale_f32_32x32x64_f8f6f4 per (32 d x 32 queries) and key tile.
+ * Reduced precision (3 mantissa bits on q, k, P and v): own tolerance, DESIGN.md 5.  Replaces the call sites of
+ * hi3d_attn_d64 (sgm/modules/attention.py:332-336, 427-439) when the caller opts in (HI3D_ATTN_FP8=1).
+ * ws: hi3d_attn_quant_qk's output; ws_v: hi3d_attn_fp8_v_workspace_bytes(B, H, S) bytes, 256-byte aligned.   */
+int64_t hi3d_attn_fp8_v_workspace_bytes(int32_t B, int32_t H, int32_t S);
+int hi3d_attn_quant_v(const void* v, void* ws_v, int32_t B, int32_t H, int32_t S, int32_t ldv, void* stream);
+int hi3d_attn_d64_fp8(const void* ws, const void* ws_v, void* out, int32_t B, int32_t H, int32_t S, int32_t ldo, void* stream);
+
 /* vt[b][h][d][s] = v[(b*S+s)*ldv + h*64 + d]  ; S_pad % 64 == 0, pad = 0    */
 int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
                      int32_t S_pad, int32_t ldv, void* stream);

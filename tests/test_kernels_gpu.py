@@ -383,6 +383,72 @@ def test_attention_d64_fp8qk(dev, B, H, S):
     assert cos > 0.995 and rms < 8e-2
 
 
+def _fp8_attention_restated(q, k, v):
+    """CPU restatement of attn_d64_fp8_kernel<PV8 = true>: q / k as _mx_e4m3; v quantised per (d, 64-key tile) with the
+    shared exponent floor(log2 amax) - 7; P = exp2(s - m) * 8 rounded to e4m3 (the kernel's reference point m may lag the
+    row maximum by a few powers of two -- e4m3's relative step does not depend on that), row sums from the unrounded P."""
+    B, H, S, _ = q.shape
+    Sp = (S + 63) // 64 * 64
+    vp = torch.zeros((B, H, Sp, 64)); vp[:, :, :S] = v
+    vt = vp.reshape(B, H, Sp // 64, 64, 64).transpose(-1, -2)                    # [B, H, tile, d, key]
+    vq = _mx_e4m3(vt.reshape(B, H, Sp // 64, 64 * 64), block=64).reshape(B, H, Sp // 64, 64, 64).transpose(-1, -2).reshape(B, H, Sp, 64)[:, :, :S]
+    s = (_mx_e4m3(q) @ _mx_e4m3(k).transpose(-1, -2)) * math.log(2.0)
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    pq = (p * 8.0).to(torch.float8_e4m3fn).float() / 8.0
+    return (pq @ vq) / p.sum(-1, keepdim=True)
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 1000), (1, 1, 70), (1, 3, 2048), (2, 5, 16384)])
+def test_attention_d64_fp8_both_products(dev, B, H, S):
+    """BASELINE config 5, full form: Q K^T and P V on the fp8 matrix path (e4m3 q, k, P, v; e8m0 scales), up to the
+    benchmarked S = 16384.  (a) the kernel computes the stated quantised attention: vs its CPU restatement 5e-2 of the
+    output range (S <= 2048; the restatement rounds P against the true row maximum, the kernel against its lagging reference
+    point); (b) fidelity vs unquantised fp32 attention, this path's own stated tolerance: cosine >= 0.99 and rms error
+    <= 12 % of the output rms (3 mantissa bits on every operand of both products)."""
+    from hi3d_hip import ops
+    C = H * 64
+    qkv = rnd((B * S, 3 * C), 43)
+    qkv[:, :C] *= ops.Q_PRESCALE
+    qkv = bf(qkv)
+    out = ops.self_attention_fused_qkv_fp8(qkv.to(dev), B, S, H).float()
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    if S <= 2048:
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * math.log(2.0), dim=-1) @ v).transpose(1, 2).reshape(B * S, C)
+        ref_q = _fp8_attention_restated(q, k, v).transpose(1, 2).reshape(B * S, C)
+        rq = relerr(out.cpu(), ref_q)
+    else:                                   # fp32 reference on the GPU (2 x 5 x 16384^2 scores: 10 GB in fp32, chunked over heads)
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+        ref = torch.cat([(torch.softmax((qd[:, h:h + 1] @ kd[:, h:h + 1].transpose(-1, -2)) * math.log(2.0), dim=-1) @ vd[:, h:h + 1])
+                         for h in range(H)], dim=1).transpose(1, 2).reshape(B * S, C)
+        rq = float("nan")
+    o, r = out.to(ref.device), ref
+    cos = F.cosine_similarity(o.flatten(), r.flatten(), dim=0).item()
+    rms = ((o - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+    mx = ((o - r).abs().max() / r.abs().max()).item()
+    print(f"fp8 attention B{B} H{H} S{S}: vs restatement {rq:.4f}; vs fp32: cos {cos:.5f} rms {rms:.4f} max {mx:.4f}")
+    assert not (rq > 5e-2)
+    assert cos > 0.99 and rms < 0.12
+
+
+def test_attention_d64_fp8qk_S16384(dev):
+    """The fp8 score product at the benchmarked sequence length (never checked beyond S = 2048): B = 2, H = 5,
+    S = 16384 vs fp32 attention computed on the GPU; the stated tolerance of that path (cos >= 0.995, rms <= 8 %)."""
+    from hi3d_hip import ops
+    B, H, S = 2, 5, 16384
+    C = H * 64
+    qkv = rnd((B * S, 3 * C), 47)
+    qkv[:, :C] *= ops.Q_PRESCALE
+    qkv = bf(qkv).to(dev)
+    out = ops.self_attention_fused_qkv_fp8qk(qkv, B, S, H).float()
+    q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    ref = torch.cat([(torch.softmax((q[:, h:h + 1] @ k[:, h:h + 1].transpose(-1, -2)) * math.log(2.0), dim=-1) @ v[:, h:h + 1])
+                     for h in range(H)], dim=1).transpose(1, 2).reshape(B * S, C)
+    cos = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    rms = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"fp8-qk attention S=16384: cos {cos:.5f} rms {rms:.4f}")
+    assert cos > 0.995 and rms < 8e-2
+
+
 @pytest.mark.parametrize("case", ["huge_logits", "all_very_negative", "late_outlier_ragged", "rising_max", "first_tile_outlier"])
 def test_attention_d64_reference_point_edge_cases(dev, case):
     """The kernel's softmax does not track the true row maximum (it checks row sums and moves the

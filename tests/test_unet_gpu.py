@@ -254,17 +254,27 @@ def test_fused_graph_step_equals_generic_step(dev):
     assert rel < 6e-2 and cos > 0.999
 
 
-def test_unet_fp8_qk_attention_path(dev, monkeypatch):
-    """BASELINE config 5 (fp8 MFMA attention + bf16 conv): the full-width UNet with every spatial attention's
-    score product on the e4m3 / MX-scaled matrix path.  Separately stated tolerance for this reduced-precision
-    option: output cosine >= 0.998 and max-abs error <= 8e-2 x max-abs reference (bf16 default: 0.9995 / 4e-2)."""
-    monkeypatch.setenv("HI3D_ATTN_FP8QK", "1")
+@pytest.mark.parametrize("mode", ["fp8qk", "fp8"])
+def test_unet_fp8_attention_paths(dev, monkeypatch, mode):
+    """BASELINE config 5 (fp8 MFMA attention + bf16 conv): the full-width UNet with every spatial attention's score product
+    (fp8qk) or both products (fp8) on the e4m3 / e8m0-scaled matrix path.  Separately stated tolerances for these
+    reduced-precision options: fp8qk cosine >= 0.998, max-abs error <= 8e-2 x max-abs reference; fp8 0.995 / 1.2e-1 (bf16
+    default: 0.9995 / 4e-2).  The option really switches kernels: the output differs from the bf16 run's."""
     fx = load("unet_s1_lat16")
-    m = build_unet(fx, dev)
-    assert m.runtime(dev).attn_fp8qk
     i = {k: v.to(dev) for k, v in fx["inputs"].items()}
-    out = m(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
-            image_only_indicator=i["image_only_indicator"])
+    run = lambda m: m(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
+                      image_only_indicator=i["image_only_indicator"])
+    monkeypatch.setenv("HI3D_ATTN_FP8QK", "0"); monkeypatch.setenv("HI3D_ATTN_FP8", "0")
+    base = run(build_unet(fx, dev))
+    monkeypatch.setenv("HI3D_ATTN_FP8QK", "1" if mode == "fp8qk" else "0")
+    monkeypatch.setenv("HI3D_ATTN_FP8", "1" if mode == "fp8" else "0")
+    m = build_unet(fx, dev)
+    rt = m.runtime(dev)
+    assert rt.attn_fp8qk == (mode == "fp8qk") and rt.attn_fp8 == (mode == "fp8")
+    out = run(m)
     rel, cos = stats(out, fx["output"])
-    print(f"fp8-qk UNet: rel {rel:.4f} cos {cos:.6f}")
-    assert rel < 8e-2 and cos > 0.998
+    d = (out.float() - base.float()).abs().max().item()
+    print(f"{mode} UNet: rel {rel:.4f} cos {cos:.6f}; max |out - bf16 run| {d:.3e}")
+    assert d > 0
+    tol, cmin = {"fp8qk": (8e-2, 0.998), "fp8": (1.2e-1, 0.995)}[mode]
+    assert rel < tol and cos > cmin
