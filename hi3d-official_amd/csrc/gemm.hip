@@ -18,6 +18,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -28,6 +29,7 @@ struct GemmParams {
   int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8;
   int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW, pad;
   int nbm, nbn;
+  int gn;      // tile raster: column groups of gn n-tiles, m walked inside a group (0 / >= nbn: one group = n fastest over the row)
   int abl;     // timing ablations (HI3D_GEMM_ABL; wrong results by design): 1 = output stores dropped, 2 = no epilogue at all
 };
 
@@ -71,7 +73,19 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = lid % p.nbn, tm = lid / p.nbn;   // n fastest: measured 15x less L2->fabric fetch than m fastest
+  // logical id -> tile.  n fastest (measured 15x less L2 -> fabric fetch than m fastest); and when the weight matrix does not
+  // fit an XCD's 4 MB L2 (GEGLU: 6.5 - 26 MB; round-2 PMC: W re-streamed from the Infinity Cache for every pair of m-tiles,
+  // 15x its size per launch), in COLUMN GROUPS of gn n-tiles: the blocks resident on an XCD cover (32 / gn) m-tiles x gn
+  // n-tiles, the group's slice of W (gn * BN * K * 2 bytes <= ~2 MB) stays in L2 while m is walked, and an A tile is shared
+  // by the gn blocks that run side by side.  Bijective for any nbm, nbn, gn (last group narrower).
+  int tn, tm;
+  if (p.gn <= 0 || p.gn >= p.nbn) {
+    tn = lid % p.nbn; tm = lid / p.nbn;
+  } else {
+    const int per = p.gn * p.nbm, g = lid / per;
+    const int gw = min(p.gn, p.nbn - g * p.gn), rem = lid - g * per;
+    tm = rem / gw; tn = g * p.gn + rem - tm * gw;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
 
@@ -761,9 +775,19 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 #endif
 }
 
+// debug capture (hi3d_debug_gemm_launch_info): the launch that hi3d_gemm_bf16 WOULD make -- kernel instantiation, geometry,
+// packed kernel argument -- written here instead of launched.  Used by hi3d_hip/devtools/isa_stress.py, which re-assembles
+// the kernel's device code with timing perturbations and launches it through the HIP module API.
+struct GemmCapture { GemmParams p; int grid, block, smem, WM, NT, NS, AMODE, EPI, PP; };
+thread_local GemmCapture* g_capture = nullptr;
+
 template <int WM, int NT, int NS, int AMODE, int EPI, bool PP = false>
 int launch(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2 * ((32 * NT * 4 + 1023) / 1024 * 1024);   // ring + bias / row-vector slots
+  if (g_capture) {
+    *g_capture = GemmCapture{p, p.nbm * p.nbn, WM * 128, smem, WM, NT, NS, AMODE, EPI, PP ? 1 : 0};
+    return HI3D_OK;
+  }
   static bool attr_done[HI3D_MAX_DEVICES] = {};
   if (int rc = hi3d_raise_lds_limit((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>, smem, attr_done)) return rc;
   hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>), dim3(p.nbm * p.nbn), dim3(WM * 128), smem, stream, p);
@@ -878,6 +902,17 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.nbn = (d->N + tile - 1) / tile;
   p.abl = 0;
   if (const char* e = getenv("HI3D_GEMM_ABL")) p.abl = atoi(e);
+  // column-group raster for weight matrices well beyond one XCD's L2 (4 MB): groups whose W slice is <= 2 MB, at least 2 wide
+  // (dense / GEGLU and the conv gathers alike; HI3D_GEMM_GN overrides: 0 = off)
+  p.gn = 0;
+  {
+    const long wbytes = (long)d->N * d->K * 2;
+    if (wbytes > (6L << 20) && p.nbn > 2) {      // measured (profiles/r03c_gemm_gn_sweep.log): 3.3 MB matrices lose 5 %, >= 6.5 MB gain 4 - 17 %
+      long g = (2L << 20) / ((long)tile * d->K * 2);
+      p.gn = (int)(g < 2 ? 2 : g);
+    }
+    if (const char* e = getenv("HI3D_GEMM_GN")) p.gn = atoi(e);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (tile == 256) return dispatch<4, 8, 2, true>(p, d->amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);
@@ -915,4 +950,21 @@ extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
   OCC(2, 5, 2) OCC(2, 4, 2) OCC(4, 5, 3) OCC(4, 4, 3) OCC(2, 5, 3) OCC(2, 4, 3)
 #undef OCC
   return n;
+}
+
+// debug aid: what hi3d_gemm_bf16(d) would launch.  params_out receives the kernel argument (struct GemmParams, at most 512
+// bytes); info[0..9] = {bytes of the argument, grid, block, dynamic LDS bytes, WM, NT, NS, AMODE, EPI, PP} -- the template
+// arguments name the instantiation gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>.  Nothing is launched.
+extern "C" int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info) {
+  if (!params_out || !info) HI3D_FAIL(HI3D_EINVAL, "debug_gemm_launch_info: null pointer");
+  static_assert(sizeof(GemmParams) <= 512, "GemmParams grew beyond the debug buffer");
+  GemmCapture c;
+  g_capture = &c;
+  const int rc = hi3d_gemm_bf16(d, nullptr);
+  g_capture = nullptr;
+  if (rc) return rc;
+  memcpy(params_out, &c.p, sizeof(GemmParams));
+  const int v[10] = {(int)sizeof(GemmParams), c.grid, c.block, c.smem, c.WM, c.NT, c.NS, c.AMODE, c.EPI, c.PP};
+  for (int i = 0; i < 10; ++i) info[i] = v[i];
+  return HI3D_OK;
 }

@@ -139,3 +139,44 @@ def attn_kernarg(q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, scale):
     """struct AttnParams of csrc/attention.hip (4 pointers, 10 ints incl. force_exact = 0, scale * log2 e)."""
     nqt = (S_q + 255) // 256
     return struct.pack("<4Q10if", q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, nqt, 0, scale * 1.4426950408889634), nqt * H * B
+
+
+# ---- the GEMM / implicit-GEMM convolution kernel of csrc/gemm.hip --------------------------------------------------------
+def gemm_symbol(WM, NT, NS, AMODE, EPI, PP):
+    return f"_ZN12_GLOBAL__N_116gemm_bf16_kernelILi{WM}ELi{NT}ELi{NS}ELi{AMODE}ELi{EPI}ELb{PP}EEEvNS_10GemmParamsE"
+
+
+def gemm_launch_info(desc):
+    """(symbol, grid, block, dynamic LDS bytes, kernarg bytes) of the launch hi3d_gemm_bf16(desc) would make
+    (hi3d_debug_gemm_launch_info: the library's own dispatch heuristics decide, nothing is launched)."""
+    from .. import lib as _l
+    lib = _l.load()
+    buf = C.create_string_buffer(512)
+    info = (C.c_int32 * 10)()
+    _l.check(lib.hi3d_debug_gemm_launch_info(desc, buf, info), "hi3d_debug_gemm_launch_info")
+    nbytes, grid, block, smem, WM, NT, NS, AMODE, EPI, PP = list(info)
+    return gemm_symbol(WM, NT, NS, AMODE, EPI, PP), grid, block, smem, buf.raw[:nbytes]
+
+
+def launch_dyn_lds(mod, symbol, grid, block, smem, kernarg, stream):
+    """Module.launch with dynamic LDS (raises the function's limit first, as the library does)."""
+    h = mod.hip()
+    if symbol not in mod.fns:
+        fn = C.c_void_p()
+        rc = h.hipModuleGetFunction(C.byref(fn), mod.mod, symbol.encode())
+        if rc:
+            raise RuntimeError(f"hipModuleGetFunction({symbol}) -> {rc}")
+        h.hipFuncSetAttribute.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if smem > 65536:
+            rc = h.hipFuncSetAttribute(fn, 8, smem)             # hipFuncAttributeMaxDynamicSharedMemorySize
+            if rc:
+                raise RuntimeError(f"hipFuncSetAttribute -> {rc}")
+        mod.fns[symbol] = fn
+    fn = mod.fns[symbol]
+    kernarg += b"\0" * (-len(kernarg) % 8)
+    buf = C.create_string_buffer(kernarg, len(kernarg))
+    size = C.c_size_t(len(kernarg))
+    extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p).value, 2, C.cast(C.pointer(size), C.c_void_p).value, 3)
+    rc = h.hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, smem, stream, None, extra)
+    if rc:
+        raise RuntimeError(f"hipModuleLaunchKernel({symbol}) -> {rc}")

@@ -70,10 +70,11 @@ def _chk_dev(*ts):
                            "run under `torch.cuda.device(...)` / torch.cuda.set_device")
 
 
-def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
+def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
          lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
-    """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
+    """(hi3d_gemm_desc, out) of gemm(...) with the same arguments -- built, not launched (gemm() launches it; the ISA stress
+    tool hands it to hi3d_debug_gemm_launch_info).  out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
     """
@@ -105,6 +106,19 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])
     else:
         d.amode = _l.A_DENSE
+    return d, out
+
+
+def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
+         R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
+    """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
+
+    conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
+    """
+    d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
+                       a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n)
+    n_out = N // 2 if geglu else N
     prof = PROFILER
     t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")

@@ -105,6 +105,10 @@ typedef struct hi3d_gemm_desc {
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
+/* debug aid (ISA-level timing stress, hi3d_hip/devtools/isa_stress.py): the launch hi3d_gemm_bf16(d) WOULD make, not made.
+ * params_out (>= 512 bytes) <- the kernel argument; info[10] <- {its size, grid, block, dynamic LDS bytes, and the template
+ * arguments WM, NT, NS, AMODE, EPI, PP of the gemm_bf16_kernel instantiation}.                                              */
+int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info);
 
 /* ------------------------------------------------------------------------ */
 /* Attention                                                                 */

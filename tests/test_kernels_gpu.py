@@ -609,3 +609,103 @@ def test_vae_helpers(dev):
     qkv = bf(rnd((300, 3 * 128), 5))
     sc = ops.gemm(qkv.to(dev), qkv.to(dev)[:, 128:], M=300, N=300, K=128, lda=384, ldw=384, out_fp32=True)
     assert relerr(sc, qkv[:, :128].float() @ qkv[:, 128:256].float().T) < 1e-5
+
+
+def _stress_patches():
+    from hi3d_hip.devtools import isa_stress as I
+    return {k: I.PATCHES[k] for k in ("mfma_then_32_idle", "16_idle_then_mfma", "every_valu_then_2_idle", "valu_noop_after_mfma",
+                                      "barrier_then_64_idle", "sleep_after_mfma")}
+
+
+@pytest.mark.parametrize("case", ["dense_affine_pp", "geglu_pp", "geglu_k320_single_stage", "conv3x3_pp", "conv3x3_up2x", "convt3",
+                                  "small_tile", "narrow_n"])
+def test_gemm_isa_timing_stress(dev, case, tmp_path, monkeypatch):
+    """The GEMM / implicit-GEMM kernel instantiations the step dispatches (ping-pong 256 x 320 affine / GEGLU / conv gathers,
+    the single-stage GEGLU tile, the 128 x 160 and 128 x 32 tiles), re-assembled with idle wait states after / before every
+    MFMA, after every VALU instruction, adjacent MFMAs split by a VALU no-op, `s_sleep` after every MFMA and a delayed
+    barrier (hi3d_hip.devtools.isa_stress; DESIGN 4c: the class of perturbation that exposed the round-2 attention build):
+    every patched launch must reproduce the library's own output bit for bit."""
+    import os
+    from hi3d_hip import ops
+    from hi3d_hip.devtools import isa_stress as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = 5
+    if case == "dense_affine_pp":
+        M, N, K = 16384, 1920, 640
+        kw = dict(A=bf(rnd((M, K), g)).to(dev), W=bf(rnd((N, K), g + 1, 0.05)).to(dev), M=M, N=N, K=K, bias=rnd((N,), g + 2).to(dev),
+                  R1=bf(rnd((M, N), g + 3)).to(dev))
+    elif case == "geglu_pp":
+        M, N, K = 32768, 5120, 640
+        kw = dict(A=bf(rnd((M, K), g)).to(dev), W=bf(rnd((N, K), g + 1, 0.05)).to(dev), M=M, N=N, K=K, bias=rnd((N,), g + 2).to(dev), geglu=True)
+    elif case == "geglu_k320_single_stage":
+        M, N, K = 65536, 2560, 320
+        kw = dict(A=bf(rnd((M, K), g)).to(dev), W=bf(rnd((N, K), g + 1, 0.05)).to(dev), M=M, N=N, K=K, bias=rnd((N,), g + 2).to(dev), geglu=True)
+    elif case in ("conv3x3_pp", "conv3x3_up2x"):
+        Fr, H, Cin, Cout, up = (8, 64, 320, 640, 0) if case == "conv3x3_pp" else (4, 32, 640, 640, 1)
+        Ho = 2 * H if up else H
+        M, K = Fr * Ho * Ho, 9 * Cin
+        kw = dict(A=bf(rnd((Fr * H * H, Cin), g)).to(dev), W=bf(rnd((Cout, K), g + 1, 0.02)).to(dev), M=M, N=Cout, K=K, bias=rnd((Cout,), g + 2).to(dev),
+                  R1=None if up else bf(rnd((M, Cout), g + 3)).to(dev), conv3x3=dict(Hin=H, Win=H, Cin=Cin, Hout=Ho, Wout=Ho, stride=1, up2x=up))
+    elif case == "convt3":
+        T, HW, Cc = 16, 1024, 640
+        M, K = 2 * T * HW, 3 * Cc
+        kw = dict(A=bf(rnd((M, Cc), g)).to(dev), W=bf(rnd((Cc, K), g + 1, 0.03)).to(dev), M=M, N=Cc, K=K, bias=rnd((Cc,), g + 2).to(dev),
+                  R2=bf(rnd((M, Cc), g + 3)).to(dev), a1=torch.full((2 * T,), 0.6, device=dev), rows_per_group=HW, convt3=dict(T=T, HW=HW, Cin=Cc))
+    elif case == "small_tile":
+        M, N, K = 4096, 1280, 1280                              # too few wide tiles: the 128 x 160 tile
+        kw = dict(A=bf(rnd((M, K), g)).to(dev), W=bf(rnd((N, K), g + 1, 0.05)).to(dev), M=M, N=N, K=K, bias=rnd((N,), g + 2).to(dev))
+    else:
+        M, N, K = 65536, 4, 320 * 9                             # the 4-channel output conv's GEMM shape (128 x 32 tile)
+        kw = dict(A=bf(rnd((M, K), g)).to(dev), W=bf(rnd((N, K), g + 1, 0.05)).to(dev), M=M, N=N, K=K, bias=rnd((N,), g + 2).to(dev), out_fp32=True)
+    ref = ops.gemm(**kw)
+    desc, out = ops.gemm_desc(**kw)
+    sym, grid, block, smem, arg = I.gemm_launch_info(desc)
+    lines = I.device_asm(os.path.join(root, "hi3d-official_amd", "csrc", "gemm.hip"))
+    st = torch.cuda.current_stream().cuda_stream
+    print(f"{case}: {sym[28:60]} grid {grid} block {block} lds {smem}")
+    for name, (when, extra, before) in _stress_patches().items():
+        pl, n = I.insert(lines, sym, when, extra, before)
+        assert n > 0, name
+        mod = I.Module(I.assemble(pl, str(tmp_path / (name + ".hsaco"))))
+        nbad = 0
+        for _ in range(6):
+            out.zero_()
+            I.launch_dyn_lds(mod, sym, grid, block, smem, arg, st)
+            torch.cuda.synchronize()
+            nbad += int(not torch.equal(out, ref))
+        mod.close()
+        assert nbad == 0, f"{case}, patch {name}: {nbad} of 6 launches differ from the unpatched kernel"
+
+
+def test_ffn2_isa_timing_stress(dev, tmp_path):
+    """The fused GEGLU feed-forward kernel (csrc/ffn2.hip: ping-pong wave halves, LDS-DMA weight rings, counted waits) under
+    the same ISA-level perturbations: bit-identical to the library's launch."""
+    import os
+    import struct
+    from hi3d_hip import ops, pack
+    from hi3d_hip.devtools import isa_stress as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    M, Cc = 32768, 320
+    x = bf(rnd((M, Cc), 3)).to(dev)
+    w1p, b1p = pack.pack_geglu(rnd((8 * Cc, Cc), 4, 0.04).to(dev), rnd((8 * Cc,), 5, 0.1).to(dev))
+    w2 = bf(rnd((Cc, 4 * Cc), 6, 0.03)).to(dev)
+    b2 = rnd((Cc,), 7, 0.1).to(dev)
+    ref = ops.ffn_geglu(x, w1p, b1p, w2, b2, M=M, C=Cc, R1=x)
+    out = torch.empty_like(ref)
+    sym = "_ZN12_GLOBAL__N_122ffn2_geglu_c320_kernelENS_10Ffn2ParamsE"
+    arg = struct.pack("<10Q6i", x.data_ptr(), w1p.data_ptr(), b1p.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), 0, 0, 0,
+                      out.data_ptr(), M, Cc, Cc, Cc, 0, 1)
+    lines = I.device_asm(os.path.join(root, "hi3d-official_amd", "csrc", "ffn2.hip"))
+    st = torch.cuda.current_stream().cuda_stream
+    for name, (when, extra, before) in _stress_patches().items():
+        pl, n = I.insert(lines, sym, when, extra, before)
+        assert n > 0, name
+        mod = I.Module(I.assemble(pl, str(tmp_path / (name + ".hsaco"))))
+        nbad = 0
+        for _ in range(6):
+            out.zero_()
+            I.launch_dyn_lds(mod, sym, (M + 127) // 128, 512, 157696, arg, st)
+            torch.cuda.synchronize()
+            nbad += int(not torch.equal(out, ref))
+        mod.close()
+        assert nbad == 0, f"ffn2, patch {name}: {nbad} of 6 launches differ from the unpatched kernel"

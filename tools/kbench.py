@@ -206,20 +206,23 @@ def bench_sweep():
     ]
     convt = [(128, 320), (64, 640), (32, 1280)]
 
+    # KB_SWEEP_ENV=HI3D_GEMM_GN sweeps the column-group width of the tile raster instead of the tile variant
+    ENV = os.environ.get("KB_SWEEP_ENV", "HI3D_GEMM_VARIANT")
+
     def run(label, fl, fn, vs):
         best = {}
         for rnd_ in range(2):
             for v in vs:
                 if v == "h":
-                    os.environ.pop("HI3D_GEMM_VARIANT", None)
+                    os.environ.pop(ENV, None)
                 else:
-                    os.environ["HI3D_GEMM_VARIANT"] = v
+                    os.environ[ENV] = v
                 try:
                     ms = timeit(fn, iters=4, warm=1)
                 except Exception as e:  # noqa: BLE001
                     ms = float("nan")
                 best[v] = min(best.get(v, 1e9), ms)
-        os.environ.pop("HI3D_GEMM_VARIANT", None)
+        os.environ.pop(ENV, None)
         cells = "  ".join(f"{v}:{best[v]:7.3f}ms {fl / best[v] / 1e9:6.0f}TF" for v in vs)
         print(f"  {label:52s} {cells}", flush=True)
 
@@ -230,7 +233,7 @@ def bench_sweep():
         geglu = kind == "geglu"
         R1 = rb(M, N) if kind == "res" else None
         out = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.bfloat16)
-        vs = variants + (["3", "5"] if geglu and not sys.argv[2:] else [])
+        vs = variants + (["3", "5"] if geglu and not sys.argv[2:] and ENV == "HI3D_GEMM_VARIANT" else [])
         run(f"dense M={M} N={N} K={K} {kind}", 2.0 * M * N * K,
             lambda: ops.gemm(A, W, M=M, N=N, K=K, bias=bias, R1=R1, geglu=geglu, out=out), vs)
         del A, W, out, R1
