@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="also log the per-shape breakdown of the profiled step")
     ap.add_argument("--no-legs", action="store_true", help="N = 1 headline run: skip the extra legs (stage 1, 32 views, fp8 scores, VAE decode)")
     ap.add_argument("--leg-steps", type=int, default=6)
+    ap.add_argument("--simulate-sp", type=int, default=4,
+                    help="N = 1: also time what ONE rank of a cfg2 x spN clip-parallel mapping computes per step (per-rank shapes, pack / "
+                         "unpack kernels, no peers: hi3d_hip.parallel.SimulatedFrameSpaceGroup); 0 = skip")
     ap.add_argument("--no-clip-parallel", action="store_true",
                     help="N > 1: skip the extra leg that runs ONE clip over all GPUs (CFG split x frame<->space all-to-all, RCCL)")
     a = ap.parse_args()
@@ -105,8 +108,16 @@ def main():
                                                  profile=not a.no_profile, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline))
     headline = stage == 2 and a.views == 16 and a.attn == "bf16"
     if headline and world == 1 and not use_dist and not a.no_legs:
+        sim = None
+        if a.simulate_sp > 1:
+            try:
+                sim = simulate_sp_leg(a, unet, a.views, 128, dev, a.simulate_sp, ms_per_step)
+            except Exception as e:                      # noqa: BLE001
+                sim = {"error": f"{type(e).__name__}: {e}"}
         del unet, sampler
         out["legs"] = run_legs(a, rank, world, dev)
+        if sim is not None:
+            out["legs"][f"clip_parallel_cfg2_sp{a.simulate_sp}_one_rank_simulated"] = sim
         unet = sampler = None
     if use_dist and world > 1 and not a.no_clip_parallel:
         # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
@@ -135,6 +146,47 @@ def main():
             sys.stdout.flush()
             os._exit(0)                  # ranks may have diverged inside the optional leg: do not wait on a teardown barrier
         torch.distributed.destroy_process_group()
+
+
+def simulate_sp_leg(a, unet, T, lat, dev, sp, single_gpu_ms):
+    """Compute side of the clip-parallel mapping without a multi-GPU node: what ONE rank of `cfg2 x sp` runs per step --
+    one CFG half, T / sp frames in the spatial sub-blocks and S / sp pixels in the temporal ones, the pack / unpack kernels
+    around every (absent) all-to-all -- timed on this GPU and compared with 1 / (2 sp) of the single-GPU step."""
+    from hi3d_hip.parallel import SimulatedFrameSpaceGroup
+    from hi3d_hip.runtime_unet import CIN_PAD
+    if T % sp or (lat // 8) ** 2 % sp:
+        return {"skipped": f"frames ({T}) / lowest-level pixels ({(lat // 8) ** 2}) not divisible by sp={sp}"}
+    rt = unet.runtime(dev)
+    g = SimulatedFrameSpaceGroup(T, sp)
+    HW = lat * lat
+    gen = torch.Generator(device=dev).manual_seed(3)
+    tok = torch.randn((g.Tl * HW, CIN_PAD), device=dev, generator=gen).to(torch.bfloat16)
+    tok[:, unet.cfg["in_channels"]:] = 0
+    tvec = torch.full((T,), 0.25 * 1.5, device=dev)
+    ctx = torch.randn((1, 1, unet.cfg["context_dim"]), device=dev, generator=gen)
+    y = torch.randn((1, unet.cfg["adm_in_channels"]), device=dev, generator=gen)
+    with torch.cuda.device(dev), torch.no_grad():
+        st = rt.clip_consts(ctx, y, torch.zeros(1, T, device=dev), T, T)
+        for _ in range(2):
+            o = rt.forward_tokens(tok, T, lat, lat, tvec, st, T, sp=g)
+        n0, b0, r0 = g.n_switches, g.bytes_moved, g.n_allreduce
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.leg_steps):
+            o = rt.forward_tokens(tok, T, lat, lat, tvec, st, T, sp=g)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / a.leg_steps * 1e3
+    if not torch.isfinite(o).all():
+        raise RuntimeError("non-finite output in the simulated rank")
+    ideal = single_gpu_ms / (2 * sp)
+    k = a.leg_steps
+    return {"mapping": f"cfg2 x sp{sp}: one of {2 * sp} ranks, peers absent (exchange replaced by a hand-back of the packed buffer)",
+            "rank_ms_per_step": round(ms, 2), "single_gpu_ms_per_step": round(single_gpu_ms, 2), "ideal_rank_ms": round(ideal, 2),
+            "compute_scaling_efficiency": round(ideal / ms, 3), "all_to_all_per_step": (g.n_switches - n0) // k,
+            "gn_allreduce_per_step": (g.n_allreduce - r0) // k,
+            "all_to_all_bytes_sent_per_rank_per_step": (g.bytes_moved - b0) // k,
+            "xgmi_time_at_153GBs_per_link_ms": round((g.bytes_moved - b0) / k / (sp - 1) / 153e9 * 1e3, 2),
+            "note": "eager launches (the single-GPU figure is a graph replay); communication time is NOT in rank_ms_per_step"}
 
 
 def run_legs(a, rank, world, dev):

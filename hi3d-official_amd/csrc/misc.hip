@@ -285,6 +285,25 @@ inline unsigned grid_for(long n, int block, long cap = 65536) {
   return (unsigned)g;
 }
 
+
+// Row permutation of a 4-D array of rows: in[d0][d1][d2][d3][row] -> out ordered by (p0, p1, p2, p3), rows of `vec` 16-byte
+// vectors.  The pack / unpack around the frame <-> space all-to-all of a clip spread over several GPUs (SURVEY 8e;
+// hi3d_hip/parallel.py: FrameSpaceGroup) -- "(b tl (dst sl)) c -> dst (b tl sl) c" and back -- which the reference never
+// needs (it has no inference parallelism) and round 2 did with ATen permute().contiguous().
+__global__ __launch_bounds__(256) void permute_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long total, int vec,
+                                                           int e0, int e1, int e2, int e3, long s0, long s1, long s2, long s3) {
+  // e* : extents of the OUTPUT dims; s* : stride (in rows) in the INPUT of each output dim
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int v = (int)(idx % vec);
+  long r = idx / vec;
+  const int i3 = (int)(r % e3); r /= e3;
+  const int i2 = (int)(r % e2); r /= e2;
+  const int i1 = (int)(r % e1); r /= e1;
+  const int i0 = (int)r;
+  out[idx] = in[(i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3) * vec + v];
+}
+
 }  // namespace
 
 extern "C" int hi3d_concat_channels(const void* a, const void* b, void* out, int64_t rows,
@@ -466,6 +485,30 @@ extern "C" int hi3d_time_mix_small(const float* x, const float* w, const float* 
   const long total = (long)B * T * HW;
   hipLaunchKernelGGL(time_mix_small_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
                      x, w, b, out, T, HW, C, ldx, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_permute_rows(const void* in, void* out, const int32_t* dims, const int32_t* perm, int32_t row_bytes, void* stream) {
+  if (!in || !out || !dims || !perm) HI3D_FAIL(HI3D_EINVAL, "permute_rows: null pointer");
+  if (row_bytes <= 0 || row_bytes % 16) HI3D_FAIL(HI3D_EALIGN, "permute_rows: rows must be a multiple of 16 bytes");
+  if (((uintptr_t)in | (uintptr_t)out) & 15) HI3D_FAIL(HI3D_EALIGN, "permute_rows: misaligned pointer");
+  long stride[4], total = 1;
+  int seen = 0;
+  for (int i = 3; i >= 0; --i) {
+    if (dims[i] <= 0) HI3D_FAIL(HI3D_EINVAL, "permute_rows: non-positive extent");
+    stride[i] = total; total *= dims[i];
+  }
+  for (int i = 0; i < 4; ++i) {
+    if (perm[i] < 0 || perm[i] > 3) HI3D_FAIL(HI3D_EINVAL, "permute_rows: perm entries must be 0..3");
+    seen |= 1 << perm[i];
+  }
+  if (seen != 15) HI3D_FAIL(HI3D_EINVAL, "permute_rows: perm is not a permutation");
+  const int vec = row_bytes / 16;
+  const long n = total * vec;
+  if ((n + 255) / 256 > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "permute_rows: grid too large");
+  hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n, vec,
+                     dims[perm[0]], dims[perm[1]], dims[perm[2]], dims[perm[3]], stride[perm[0]], stride[perm[1]], stride[perm[2]], stride[perm[3]]);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

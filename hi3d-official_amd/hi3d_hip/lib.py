@@ -21,7 +21,7 @@ EXPORTS = [
     "hi3d_cfg_prepare", "hi3d_sampler_step", "hi3d_cfg_update_x", "hi3d_sampler_step_dev", "hi3d_nchw_f32_to_nhwc_bf16",
     "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows", "hi3d_vae_posterior", "hi3d_v02_blend", "hi3d_time_mix_small", "hi3d_ffn_geglu",
     "hi3d_act_bf16", "hi3d_l2_normalize_rows", "hi3d_add_act_bf16", "hi3d_dpt_stem_conv", "hi3d_pool2_nhwc",
-    "hi3d_resize_bilinear_nhwc", "hi3d_dpt_head_out", "hi3d_depth_normalize_unshuffle", "hi3d_resample_axis",
+    "hi3d_resize_bilinear_nhwc", "hi3d_dpt_head_out", "hi3d_depth_normalize_unshuffle", "hi3d_resample_axis", "hi3d_permute_rows",
 ]
 
 A_DENSE, A_CONV3X3, A_CONVT3 = 0, 1, 2
@@ -104,6 +104,7 @@ def load():
         "hi3d_resize_bilinear_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
         "hi3d_dpt_head_out": (C.c_int, [vp, vp, C.c_float, vp, i64, i32, vp]),
         "hi3d_depth_normalize_unshuffle": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+        "hi3d_permute_rows": (C.c_int, [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, vp]),
         "hi3d_resample_axis": (C.c_int, [vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():

@@ -468,6 +468,21 @@ def resize_bilinear(x, Ho, Wo, align_corners=False):
     return y
 
 
+def permute_rows(x, dims, perm):
+    """x: contiguous tensor viewed as [dims[0], dims[1], dims[2], dims[3], row] -> the same rows in the order perm (a new
+    contiguous tensor [dims[perm[0]], ..., row]).  Rows must be a multiple of 16 bytes."""
+    import ctypes as C
+    _chk_dev(x)
+    n = dims[0] * dims[1] * dims[2] * dims[3]
+    if not x.is_contiguous() or x.numel() % n:
+        raise _l.Hi3dError("permute_rows: contiguous tensor whose size is a multiple of prod(dims) required")
+    row = x.numel() // n
+    out = torch.empty([dims[p] for p in perm] + [row], device=x.device, dtype=x.dtype)
+    _l.check(_lib.hi3d_permute_rows(_p(x), _p(out), (C.c_int32 * 4)(*dims), (C.c_int32 * 4)(*perm), row * x.element_size(), _stream()),
+             "hi3d_permute_rows")
+    return out
+
+
 def resample_image(x, kind, scale=None, shift=None):
     """x fp32 [N, C, H, W] -> fp32 [N, C, Ho, Wo]: the separable resampling `kind` of hi3d_hip/resample.py (two banded
     passes, W then H) followed by the per-channel affine y * scale[c] + shift[c] (fused into the second pass)."""

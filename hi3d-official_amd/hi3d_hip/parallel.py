@@ -155,23 +155,34 @@ class FrameSpaceGroup:
         self.bytes_moved += send.numel() * send.element_size() * (self.world - 1) // self.world
         return recv
 
+    @staticmethod
+    def _perm(x, dims, perm):
+        """rows of x viewed as dims[0..3] in the order `perm`: the HIP row-permutation kernel on the GPU (hi3d_permute_rows:
+        one pass, no ATen), torch on the CPU (the gloo tests of the layout algebra)."""
+        if x.is_cuda:
+            from . import ops
+            return ops.permute_rows(x.contiguous(), list(dims), list(perm))
+        return x.reshape(*dims, -1).permute(*perm, 4).contiguous()
+
     def frames_to_space(self, x, B, S):
         """[B*Tl*S, C] (b tl s) -> [B*T*Sl, C] (b t sl)"""
         w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
         if w == 1:
             return x
-        send = x.reshape(B, Tl, w, Sl, C).permute(2, 0, 1, 3, 4).contiguous()      # [dst][b][tl][sl][c]
+        send = self._perm(x, (B * Tl, w, Sl, 1), (1, 0, 2, 3))                    # (b tl)(dst)(sl) -> [dst][b tl][sl][c]
         recv = self._a2a(send)                                                     # [src][b][tl][sl][c]: src owns frames src*Tl..
-        return recv.permute(1, 0, 2, 3, 4).reshape(B * self.T * Sl, C)             # (b, (src tl) = t, sl); free when B == 1
+        if B > 1:                                                                  # (b, (src tl) = t, sl); nothing to move when B == 1
+            recv = self._perm(recv, (w, B, Tl * Sl, 1), (1, 0, 2, 3))
+        return recv.reshape(B * self.T * Sl, C)
 
     def space_to_frames(self, x, B, S):
         """[B*T*Sl, C] (b t sl) -> [B*Tl*S, C] (b tl s)"""
         w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
         if w == 1:
             return x
-        send = x.reshape(B, w, Tl, Sl, C).permute(1, 0, 2, 3, 4).contiguous()      # [dst = owner of frames][b][tl][sl][c]
-        recv = self._a2a(send)                                                     # [src = owner of pixels][b][tl][sl][c]
-        return recv.permute(1, 2, 0, 3, 4).reshape(B * Tl * S, C)                  # (b, tl, (src sl) = s)
+        send = x if B == 1 else self._perm(x, (B, w, Tl * Sl, 1), (1, 0, 2, 3))     # [dst = owner of frames][b][tl][sl][c]
+        recv = self._a2a(send.reshape(w, B, Tl, Sl, C))                            # [src = owner of pixels][b][tl][sl][c]
+        return self._perm(recv, (w, B * Tl, Sl, 1), (1, 0, 2, 3)).reshape(B * Tl * S, C)   # (b, tl, (src sl) = s)
 
     def allreduce_sum_(self, t):
         """in-place sum over the group: the [b, 32, 2] GroupNorm partial sums of a space-sharded 3-D norm"""
@@ -184,6 +195,31 @@ class FrameSpaceGroup:
                 dist.all_reduce(t, group=self.group)
             self.n_allreduce += 1
         return t
+
+
+class SimulatedFrameSpaceGroup(FrameSpaceGroup):
+    """The work of ONE rank of a `world`-way frame <-> space group on a single GPU, without peers: same shapes, same pack /
+    unpack kernels, same kernel sequence; the exchange itself is replaced by handing the packed buffer back (its CONTENT is then
+    not the clip's -- only timing is meaningful).  bench.py --simulate-sp uses it to measure the compute side of the
+    clip-parallel mapping (what a rank does per step vs 1 / world of the single-GPU step) where no multi-GPU node is at hand."""
+
+    def __init__(self, T, world, rank=0):
+        if T % world:
+            raise ValueError(f"num_video_frames ({T}) must be a multiple of the frame-parallel degree ({world})")
+        self.group, self.world, self.rank = None, world, rank
+        self.T, self.Tl = T, T // world
+        self.t_lo = rank * self.Tl
+        self.bytes_moved = self.n_switches = self.n_allreduce = 0
+        self._host_staged = False
+
+    def _a2a(self, send):
+        self.n_switches += 1
+        self.bytes_moved += send.numel() * send.element_size() * (self.world - 1) // self.world
+        return send
+
+    def allreduce_sum_(self, t):
+        self.n_allreduce += 1
+        return t.mul_(float(self.world))          # as if every rank contributed the same partial sums
 
 
 _SP_GROUPS = {}     # member ranks -> process group (one communicator per distinct frame-parallel group)
@@ -243,6 +279,20 @@ class ClipParallelStepper:
             self._clip = (key, pick("crossattn"), pick("vector"), cc, (c, uc))     # refs held: ids stay unique
         return self._clip[1:4]
 
+    def _buffers(self, x, cc_u, cc_c, dev):
+        """Persistent step buffers (as FusedStepper's): a token buffer for both CFG halves of this rank's frames whose
+        conditioning channels are written once per clip (hi3d_cfg_prepare), sigma pair and c_noise vectors on the device."""
+        T, Tl = self.T, self.comm.Tl
+        _, _, H, W = x.shape
+        key = (Tl, H, W, id(cc_c), id(cc_u), None if cc_c is None else cc_c._version)
+        if getattr(self, "_buf", None) is None or self._buf[0] != key:
+            from . import ops
+            from .runtime_unet import CIN_PAD
+            xl = torch.zeros((Tl, 4, H, W), device=dev, dtype=torch.float32)
+            tok = ops.cfg_prepare(xl, cc_u, cc_c, CIN_PAD, 0.0)                       # [2][Tl][HW][Cp]: concat channels set
+            self._buf = (key, xl, tok, torch.zeros(2, device=dev), torch.zeros(2 * Tl, device=dev), torch.zeros(2 * T, device=dev), (cc_c, cc_u))
+        return self._buf[1:6]
+
     @torch.no_grad()
     def step(self, x, sigmas, i, c, uc, image_only_indicator=None):
         from . import ops
@@ -255,14 +305,21 @@ class ClipParallelStepper:
         with torch.cuda.device(dev):
             ctx, y, cc = self._conds(c, uc, dev)
             st = rt.clip_consts(ctx, y, image_only_indicator, B * T, T)
-            sig = sigmas[i:i + 2].to(dev, torch.float32)
-            c_in = torch.rsqrt(sig[0] * sig[0] + 1.0)
-            xl = (x[lo:lo + Tl] * c_in)
-            xin = xl if B == 1 else torch.cat((xl, xl), 0)
-            if cc is not None:
-                xin = torch.cat((xin, cc), 1)
-            tok = ops.nchw_to_tokens(xin, CIN_PAD)
-            tvec = (0.25 * torch.log(sig[0])).expand(B * T).contiguous()
+            # step head on HIP kernels (no ATen elementwise / cat): x * c_in into the 4 latent channels of the persistent token
+            # buffer of this rank's frames, c_noise per batch row, sigma read on the device
+            if cc is None:
+                cu_l = cc_l = None
+            elif self.cfg == 2:
+                cu_l = cc_l = cc                                                      # this rank's half only (both slots: one is read)
+            else:
+                cu_l, cc_l = cc[:Tl], cc[Tl:]
+            xl, tok2, sig, tv_l, tv_full = self._buffers(x, cu_l, cc_l, dev)
+            sig.copy_(sigmas[i:i + 2])
+            xl.copy_(x[lo:lo + Tl])
+            ops.cfg_update_x(xl, tok2, sig, tv_l, Tl, HW, CIN_PAD)
+            tok = tok2 if B == 2 else tok2[self.half * Tl * HW:(self.half + 1) * Tl * HW]
+            tv_full.copy_(tv_l[:1].expand(2 * T))
+            tvec = tv_full[:B * T]
             net = rt.forward_tokens(tok, B * T, H, W, tvec, st, T, sp=self.comm)            # [B*Tl*HW, 4] fp32
             world = self.cfg * self.sp
             full = torch.empty((world * net.shape[0], net.shape[1]), device=dev, dtype=net.dtype)   # rank-major concatenation
@@ -277,7 +334,9 @@ class ClipParallelStepper:
                 net_full = full.reshape(2 * T * HW, net.shape[-1])
             else:                        # [part][b][Tl*HW][4] -> [b][part][Tl*HW][4]
                 net_full = full.reshape(self.sp, 2, Tl * HW, net.shape[-1]).transpose(0, 1).reshape(2 * T * HW, net.shape[-1])
-            scale = self.guider.scale.reshape(-1).to(dev, torch.float32).contiguous()
+            gs = self.guider.scale
+            if getattr(self, "_scale", None) is None or self._scale[0] is not gs or self._scale[1] != gs._version:
+                self._scale = (gs, gs._version, gs.reshape(-1).to(dev, torch.float32).contiguous())
             out = torch.empty_like(x)
-            ops.sampler_step_dev(x.contiguous(), out, net_full.contiguous(), scale, sig.contiguous(), T, HW, net.shape[-1])
+            ops.sampler_step_dev(x.contiguous(), out, net_full.contiguous(), self._scale[2], sig, T, HW, net.shape[-1])
             return out

@@ -372,6 +372,12 @@ int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, const void* w
                    int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
                    int32_t rows_per_group, void* stream);
 
+/* out = in.permute(perm) for a 4-D array of rows: in[dims[0]][dims[1]][dims[2]][dims[3]][row_bytes] (row_bytes % 16 == 0),
+ * out[dims[perm[0]]][dims[perm[1]]][dims[perm[2]]][dims[perm[3]]][row_bytes].  The pack / unpack around the frame <-> space
+ * all-to-all of one clip on several GPUs (the reference has no inference parallelism, README.md:56-64):
+ * "(b tl (dst sl)) c -> dst (b tl sl) c" before the exchange, "src (b tl sl) c -> b (src tl) sl c" after it.              */
+int hi3d_permute_rows(const void* in, void* out, const int32_t* dims, const int32_t* perm, int32_t row_bytes, void* stream);
+
 /* One axis of a separable image resampling with banded taps (built on the host by hi3d_hip/resample.py):
  *   out[outer][o][inner] = scale[c] * sum_{t < ntap} w[o][t] * in[outer][start[o] + t][inner] + shift[c]
  *   c = (outer_index / chan_div) % chan_mod ; scale == shift == NULL: no affine.  All fp32.

@@ -112,3 +112,22 @@ def test_clip_parallel_step_matches_single_gpu(dev, world, cfg):
             assert n_sw == 2 * 2 * (nres + nattn) and n_ar == 2 * 2 * nres       # two steps
         else:
             assert n_sw == 0 and n_ar == 0
+
+
+def test_permute_rows_and_simulated_group(dev):
+    """hi3d_permute_rows (the pack / unpack of the frame <-> space exchange) vs torch permute, and the single-GPU stand-in
+    group bench.py --simulate-sp uses: same shapes as a real rank, finite output."""
+    import torch
+    from hi3d_hip import ops
+    from hi3d_hip.parallel import SimulatedFrameSpaceGroup
+    x = torch.randn((2 * 3 * 4 * 5, 64), generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(dev)
+    for perm in ((1, 0, 2, 3), (2, 0, 1, 3), (3, 2, 1, 0), (0, 1, 2, 3)):
+        ref = x.reshape(2, 3, 4, 5, 64).permute(*perm, 4).contiguous()
+        assert torch.equal(ops.permute_rows(x, [2, 3, 4, 5], list(perm)), ref)
+    g = SimulatedFrameSpaceGroup(8, 4)
+    B, S, C = 2, 16, 64
+    t = torch.randn((B * g.Tl * S, C), generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(dev)
+    sp = g.frames_to_space(t, B, S)
+    assert sp.shape == (B * 8 * (S // 4), C)
+    back = g.space_to_frames(sp, B, S)
+    assert back.shape == t.shape and g.n_switches == 2
