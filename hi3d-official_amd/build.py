@@ -136,6 +136,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ISA_STRESSED = ("attention.hip", "gemm.hip", "ffn2.hip")
+
+
+def build_isa(verbose=True):
+    """Device assembly of the translation units the ISA timing-stress tests patch (hi3d_hip/devtools/isa_stress.py), cached
+    under hi3d_hip/_isa/ keyed by a source digest -- compiled here so the GPU suite does not spend its time in hipcc."""
+    sys.path.insert(0, ROOT)
+    from hi3d_hip.devtools import isa_stress
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(len(ISA_STRESSED)) as ex:
+        for f, lines in zip(ISA_STRESSED, ex.map(lambda f: isa_stress.device_asm(os.path.join(CSRC, f)), ISA_STRESSED)):
+            if verbose:
+                print(f"[hi3d build] _isa/{f}.s ({len(lines)} lines)", file=sys.stderr)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     build_torch_ops(force="--force" in sys.argv)
+    build_isa()

@@ -23,8 +23,42 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def device_asm(hip_file, include_dirs=()):
-    """gfx950 device assembly of a .hip translation unit (list of lines)."""
+ISA_CACHE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_isa")
+
+
+def _source_digest(hip_file):
+    """sha256 over the translation unit and every header beside it (what the device code can depend on)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in [hip_file] + sorted(glob.glob(os.path.join(os.path.dirname(hip_file), "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def device_asm(hip_file, include_dirs=(), cache=True):
+    """gfx950 device assembly of a .hip translation unit (list of lines), compiled with the flags of build.py.
+    Cached under hi3d_hip/_isa/ keyed by a digest of the sources: `build.py` fills the cache in the build container
+    (gemm.hip takes ~50 s of hipcc), so the GPU suite only patches and re-assembles."""
+    cs = os.path.join(ISA_CACHE, os.path.basename(hip_file) + ".s")
+    dig = _source_digest(hip_file) if cache else None
+    if cache and os.path.exists(cs) and os.path.exists(cs + ".digest") and open(cs + ".digest").read().strip() == dig:
+        return open(cs).read().split("\n")
+    lines = _compile_device_asm(hip_file, include_dirs)
+    if cache:
+        try:
+            os.makedirs(ISA_CACHE, exist_ok=True)
+            with open(cs, "w") as fh:
+                fh.write("\n".join(lines))
+            with open(cs + ".digest", "w") as fh:
+                fh.write(dig)
+        except OSError:
+            pass
+    return lines
+
+
+def _compile_device_asm(hip_file, include_dirs=()):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-S",

@@ -478,8 +478,12 @@ def permute_rows(x, dims, perm):
         raise _l.Hi3dError("permute_rows: contiguous tensor whose size is a multiple of prod(dims) required")
     row = x.numel() // n
     out = torch.empty([dims[p] for p in perm] + [row], device=x.device, dtype=x.dtype)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_permute_rows(_p(x), _p(out), (C.c_int32 * 4)(*dims), (C.c_int32 * 4)(*perm), row * x.element_size(), _stream()),
              "hi3d_permute_rows")
+    if prof:
+        prof.end("permute_rows", 0.0, 2.0 * x.numel() * x.element_size(), t0)
     return out
 
 
