@@ -225,6 +225,27 @@ class SimulatedFrameSpaceGroup(FrameSpaceGroup):
 _SP_GROUPS = {}     # member ranks -> process group (one communicator per distinct frame-parallel group)
 
 
+def clip_parallel_groups(group=None, cfg=2, sp_group=None):
+    """(sp, half, part, sp_group) of the calling rank in a cfg x sp mapping of `group` (rank r -> divmod(r, sp)).
+
+    One sub-group per CFG half carries the frame<->space traffic.  It is created with group-local synchronisation: only the
+    MEMBERS of a sub-group call new_group, so `group` may itself be a proper sub-group of the job (e.g. 2 clips x 4 GPUs)
+    without the ranks outside it having to make a matching call; cached per member list (steppers built one after another
+    on the same ranks share their communicators).  `sp_group=` hands in a group made elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if cfg not in (1, 2) or world % cfg:
+        raise ValueError(f"cfg split {cfg} does not divide the group of {world} ranks")
+    sp = world // cfg
+    half, part = divmod(rank, sp)
+    ranks_all = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    mine = tuple(ranks_all[half * sp + q] for q in range(sp))
+    if sp_group is None:
+        sp_group = _SP_GROUPS.get(mine)
+        if sp_group is None:
+            sp_group = _SP_GROUPS[mine] = dist.new_group(list(mine), use_local_synchronization=True)
+    return sp, half, part, sp_group
+
+
 class ClipParallelStepper:
     """ONE clip's Euler-EDM + CFG step on cfg x sp GPUs (the recommended 8-GPU mapping is
     2 (CFG pair) x 4 (frame <-> space groups)).  Rank r of `group` is (half, part) = divmod(r, sp):
@@ -242,22 +263,7 @@ class ClipParallelStepper:
         from . import ops  # noqa: F401  (needs the HIP library: GPU only)
         self.unet, self.guider, self.T, self.cfg = unet, guider, T, cfg
         self.group = group
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        if cfg not in (1, 2) or world % cfg:
-            raise ValueError(f"cfg split {cfg} does not divide the group of {world} ranks")
-        self.sp = world // cfg
-        self.half, self.part = divmod(rank, self.sp)
-        # one sub-group per CFG half for the frame<->space traffic.  Created with group-local synchronisation: only the
-        # MEMBERS of a sub-group call new_group, so `group` may itself be a proper sub-group of the job (e.g. 2 clips x 4
-        # GPUs) without the ranks outside it having to make a matching call; cached per member list (steppers built one
-        # after another on the same ranks share their communicators).  `sp_group=` hands in a group made elsewhere.
-        ranks_all = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-        mine = tuple(ranks_all[self.half * self.sp + q] for q in range(self.sp))
-        if sp_group is None:
-            sp_group = _SP_GROUPS.get(mine)
-            if sp_group is None:
-                sp_group = _SP_GROUPS[mine] = dist.new_group(list(mine), use_local_synchronization=True)
-        self.sp_group = sp_group
+        self.sp, self.half, self.part, self.sp_group = clip_parallel_groups(group, cfg, sp_group)
         self.comm = FrameSpaceGroup(T, self.sp_group)
         self.gather_bytes = 0
         self._host_staged = dist.get_backend(group) == "gloo"

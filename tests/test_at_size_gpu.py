@@ -184,11 +184,8 @@ def test_softmax_rows_at_limit(dev):
 
 # ------------------------------------------------------------------ networks at size
 def _build_unet(fx, dev):
-    from hi3d_hip import synth
-    from sgm.modules.diffusionmodules.video_model import VideoUNet
-    m = VideoUNet(**fx["cfg"])
-    synth.fill_module_(m, fx["weight_seed"], prefix=fx["key_prefix"])
-    return m.to(dev)
+    from conftest import synth_unet          # seeded weights drawn once per session, a fresh module per call
+    return synth_unet(fx, dev)
 
 
 @pytest.mark.parametrize("attn", ["bf16", "fp8qk", "fp8"])

@@ -193,3 +193,37 @@ def test_unet_frame_space_sharded_equals_unsharded_oracle():
     layers = [L for blk in bi + [mid] + bo for L in blk]
     nres, nattn = sum(L[0] == "res" for L in layers), sum(L[0] == "attn" for L in layers)
     assert res[0][1] == 2 * (nres + nattn) and res[0][2] == 2 * nres
+
+
+def _groups_job(rank, world):
+    """cfg x sp sub-groups of the clip-parallel mapping: on the whole job (4 ranks = cfg 2 x sp 2), and with TWO clips side
+    by side (parents {0,1} and {2,3}, each cfg 1 x sp 2) -- the parents and the sub-groups are created by their members
+    only (group-local synchronisation), the way two steppers on disjoint GPUs of one job do it."""
+    from hi3d_hip.parallel import clip_parallel_groups
+    out = {}
+    sp, half, part, g = clip_parallel_groups(None, cfg=2)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, group=g)
+    out["whole"] = (sp, half, part, dist.get_process_group_ranks(g), t.item())
+    sp2, half2, part2, g2 = clip_parallel_groups(None, cfg=2)              # cached: the same communicator
+    out["cached"] = g2 is g
+    members = [0, 1] if rank < 2 else [2, 3]
+    parent = dist.new_group(members, use_local_synchronization=True)
+    sp, half, part, g = clip_parallel_groups(parent, cfg=1)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, group=g)
+    out["two_clips"] = (sp, half, part, dist.get_process_group_ranks(g), t.item())
+    sp, half, part, g = clip_parallel_groups(parent, cfg=2)               # sp = 1: a group of one
+    out["cfg_only"] = (sp, half, part, dist.get_process_group_ranks(g))
+    return out
+
+
+def test_clip_parallel_group_membership_4_ranks():
+    res = spawn(_groups_job, 4)
+    for r in range(4):
+        half, part = divmod(r, 2)
+        mem = [2 * half, 2 * half + 1]
+        assert res[r]["whole"] == (2, half, part, mem, float(sum(mem)))
+        assert res[r]["cached"]
+        assert res[r]["two_clips"] == (2, 0, r % 2, mem, float(sum(mem)))
+        assert res[r]["cfg_only"] == (1, r % 2, 0, [r])

@@ -90,7 +90,13 @@ def _reference(dev):
     return x.cpu(), fx
 
 
-@pytest.mark.parametrize("world,cfg", [(2, 1), (4, 2)])
+# (4, 2) -- both axes at once -- costs four minutes on ONE GPU (four processes time-slicing it, every payload staged through
+# the host): opt-in with HI3D_SLOW_TESTS=1.  The default pair covers each axis with the real HIP UNet; the 4-rank group
+# arithmetic (sub-groups made by their members only) is covered on gloo in tests/test_parallel_cpu.py.
+_CASES = [(2, 1), (2, 2)] + ([(4, 2)] if os.environ.get("HI3D_SLOW_TESTS") == "1" else [])
+
+
+@pytest.mark.parametrize("world,cfg", _CASES)
 def test_clip_parallel_step_matches_single_gpu(dev, world, cfg):
     ref, fx = _reference(dev)
     mgr = mp.Manager()

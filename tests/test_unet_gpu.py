@@ -28,11 +28,8 @@ def stats(a, b):
 
 
 def build_unet(fx, dev):
-    from hi3d_hip import synth
-    from sgm.modules.diffusionmodules.video_model import VideoUNet
-    m = VideoUNet(**fx["cfg"])
-    synth.fill_module_(m, fx["weight_seed"], prefix=fx["key_prefix"])
-    return m.to(dev)
+    from conftest import synth_unet          # seeded weights drawn once per session, a fresh module per call
+    return synth_unet(fx, dev)
 
 
 @pytest.mark.parametrize("name", ["unet_tiny_s1", "unet_tiny_s2_ioi", "unet_s1_lat16", "unet_s2_lat16"])
