@@ -31,6 +31,11 @@ struct GemmParams {
   int nbm, nbn;
   int gn;      // tile raster: column groups of gn n-tiles, m walked inside a group (0 / >= nbn: one group = n fastest over the row)
   int abl;     // timing ablations (HI3D_GEMM_ABL; wrong results by design): 1 = output stores dropped, 2 = no epilogue at all
+  // split-K (long-K launches with too few tiles for the chip: the 8x8 / 16x16 levels of stage 1, the ranks of a clip-parallel
+  // job): the grid is ksplit x (nbm * nbn); block (ks, tile) accumulates K steps [ks * nk_split, (ks + 1) * nk_split) -- whole
+  // channel slabs for the conv gathers, whose K walks the taps innermost -- into the fp32 partial tile ks of `out`
+  // ([ksplit][M][ldo], no bias / residual); splitk_combine_kernel sums the partials in a fixed order and applies the epilogue.
+  int ksplit, nk_split;
 };
 
 constexpr int BK = 64;
@@ -68,11 +73,14 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // ---- block -> tile, XCD-aware: consecutive logical ids (which share the A tile
   // and sweep W) stay on one XCD's L2.  Bijective for any grid size.
   const int nblk = p.nbm * p.nbn;
-  int lid;
+  int lid, ks = 0;
   {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    int bid = blockIdx.x;
+    if (p.ksplit > 1) { ks = bid / nblk; bid -= ks * nblk; }     // K split outermost: the tiles of one split run side by side
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int nk = p.ksplit > 1 ? p.nk_split : p.K / BK;
   // logical id -> tile.  n fastest (measured 15x less L2 -> fabric fetch than m fastest); and when the weight matrix does not
   // fit an XCD's 4 MB L2 (GEGLU: 6.5 - 26 MB; round-2 PMC: W re-streamed from the Infinity Cache for every pair of m-tiles,
   // 15x its size per launch), in COLUMN GROUPS of gn n-tiles: the blocks resident on an XCD cover (32 / gn) m-tiles x gn
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   int a_p0[4], a_p1[4];         // up2x only: output pixel coordinates
   const char* a_origin;
   if (AMODE == HI3D_A_DENSE) {
-    a_origin = p.A + (long)m0 * p.lda * 2;
+    a_origin = p.A + (long)m0 * p.lda * 2 + (long)ks * nk * (BK * 2);     // (split-K: this block's first K chunk)
   } else if (AMODE == HI3D_A_CONV3X3) {
     const int f0 = m0 / (p.Hout * p.Wout);
     // origin shifted back by one row + one pixel so that every tap offset is >= 0
@@ -159,9 +167,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     b_voff[i] = (n0 + j < p.N) ? (unsigned)(j * p.ldw * 2 + chunk * 16) : INV;
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_origin, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)n0 * p.ldw * 2), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.W + (long)n0 * p.ldw * 2 + (AMODE == HI3D_A_DENSE ? (long)ks * nk * (BK * 2) : 0L)), 0, 0x7fffffff, 0x00020000);
 
-  int tap = 0, c0 = 0;   // conv modes: current tap and channel offset of the K chunk
+  // conv modes: current tap and channel offset of the K chunk (split-K starts at a slab boundary: nk is a multiple of the taps)
+  int tap = 0, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) * BK;
 
   // LDS-DMA pieces [LO, HI) of K chunk `kt` into ring slot `st`: pieces 0..3 are this wave's A rows, 4.. its W rows
   // (the ping-pong loop spreads the pieces of a stage over its phases; the plain loops issue them all at once)
@@ -320,7 +330,6 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // it requests them one store pass ahead in the epilogue (below).
   constexpr bool RES_EARLY = NT <= 5;
 
-  const int nk = p.K / BK;
   const int pf_kt = nk >= 2 ? nk - 2 : 0;
   int st = 0;
   if constexpr (PP) {
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     const int wcol0 = n0_out + wn * WOUT;                                // first output column of this wave
     const long wrow0 = (long)m0 + wm * 64;                               // first row of this wave
     const __amdgpu_buffer_rsrc_t rsOw =
-        __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
     // chunk i of a pass = lane + 64 i: slab row / column, the same in all four passes -- its LDS, bias, output and
     // residual offsets are computed once per tile (the store loop was VALU-bound on this index arithmetic: ~80
     // instructions per chunk, 20 chunks per wave; the accumulators leave ~30 registers for it)
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     return;
   }
   const __amdgpu_buffer_rsrc_t rsO =
-      __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)m0 * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (((long)ks * p.M + m0) * p.ldo + n0_out) * osz, 0, 0x7fffffff, 0x00020000);
   __syncthreads();                                 // every wave is done with the operand ring
 #pragma unroll
   for (int half = 0; half < NPASS; ++half) {
@@ -785,12 +794,12 @@ template <int WM, int NT, int NS, int AMODE, int EPI, bool PP = false>
 int launch(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NS * (WM * 64 * BK * 2 + 32 * NT * BK * 2) + 2 * ((32 * NT * 4 + 1023) / 1024 * 1024);   // ring + bias / row-vector slots
   if (g_capture) {
-    *g_capture = GemmCapture{p, p.nbm * p.nbn, WM * 128, smem, WM, NT, NS, AMODE, EPI, PP ? 1 : 0};
+    *g_capture = GemmCapture{p, p.nbm * p.nbn * (p.ksplit > 1 ? p.ksplit : 1), WM * 128, smem, WM, NT, NS, AMODE, EPI, PP ? 1 : 0};
     return HI3D_OK;
   }
   static bool attr_done[HI3D_MAX_DEVICES] = {};
   if (int rc = hi3d_raise_lds_limit((const void*)gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>, smem, attr_done)) return rc;
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>), dim3(p.nbm * p.nbn), dim3(WM * 128), smem, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>), dim3(p.nbm * p.nbn * (p.ksplit > 1 ? p.ksplit : 1)), dim3(WM * 128), smem, stream, p);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }
@@ -810,7 +819,62 @@ int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
   HI3D_FAIL(HI3D_EINVAL, "gemm: bad amode");
 }
 
+// ---- split-K second pass: out = a1 * (sum_s part[s] + bias + rowvec[g] + R1) + a2 * R2 (the AFFINE epilogue of the kernel
+// above, same order of operations), partials summed in split order -- bitwise reproducible.  One thread = 4 columns of a row.
+struct CombineParams {
+  const float* part; const float* bias; const float* rowvec; const unsigned short* R1; const unsigned short* R2;
+  const float* a1; const float* a2; void* out;
+  int M, N, S, ldo, ldr1, ldr2, ldrv, rpg, out_fp32;
+};
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const CombineParams c) {
+  const int nq = c.N >> 2;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)c.M * nq) return;
+  const int m = (int)(id / nq), n = (int)(id - (long)m * nq) * 4;
+  const long plane = (long)c.M * c.N;
+  const float* pp = c.part + (long)m * c.N + n;
+  f32x4 v = *(const f32x4*)pp;
+  for (int s = 1; s < c.S; ++s) { const f32x4 t = *(const f32x4*)(pp + s * plane); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+  const int g = m / c.rpg;
+  if (c.bias) { const f32x4 b = *(const f32x4*)(c.bias + n); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+  if (c.rowvec) { const f32x4 r = *(const f32x4*)(c.rowvec + (long)g * c.ldrv + n); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+  if (c.R1) {
+    const u32x2 r = *(const u32x2*)(c.R1 + (long)m * c.ldr1 + n);
+    v[0] += bf16_to_f32(r[0] & 0xffff); v[1] += bf16_to_f32(r[0] >> 16); v[2] += bf16_to_f32(r[1] & 0xffff); v[3] += bf16_to_f32(r[1] >> 16);
+  }
+  if (c.a1) { const float s1 = c.a1[g]; v[0] *= s1; v[1] *= s1; v[2] *= s1; v[3] *= s1; }
+  if (c.R2) {
+    const float s2 = c.a2 ? c.a2[g] : 1.0f;
+    const u32x2 r = *(const u32x2*)(c.R2 + (long)m * c.ldr2 + n);
+    v[0] += s2 * bf16_to_f32(r[0] & 0xffff); v[1] += s2 * bf16_to_f32(r[0] >> 16); v[2] += s2 * bf16_to_f32(r[1] & 0xffff); v[3] += s2 * bf16_to_f32(r[1] >> 16);
+  }
+  if (c.out_fp32) *(f32x4*)((float*)c.out + (long)m * c.ldo + n) = v;
+  else *(u32x2*)((unsigned short*)c.out + (long)m * c.ldo + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+}
+
+// caller-provided scratch for the fp32 partial tiles, one per device (hi3d_gemm_set_workspace); no workspace = no split-K
+struct GemmWorkspace { void* ptr; long bytes; };
+GemmWorkspace g_ws[HI3D_MAX_DEVICES] = {};
+
+// K split of a launch with `tiles` 128-row tiles: as many splits (<= 8) as keep tiles * S within the chip's 512 block slots
+// (256 CUs x 2 resident blocks), each at least 8 K steps long and a whole number of `units` (K steps for dense A, 64-channel
+// slabs for the conv gathers)
+int splitk_choose(long tiles, int units, int ksteps_per_unit, long part_bytes, long ws_bytes) {
+  int best = 1;
+  for (int S = 2; S <= 8; ++S)
+    if (units % S == 0 && (units / S) * ksteps_per_unit >= 8 && tiles * S <= 576 && part_bytes * S <= ws_bytes) best = S;
+  return best;
+}
+
 }  // namespace
+
+extern "C" int hi3d_gemm_set_workspace(void* ptr, int64_t bytes) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HI3D_MAX_DEVICES) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: no current device");
+  if (bytes < 0 || (ptr == nullptr) != (bytes == 0) || ((uintptr_t)ptr & 15)) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: bad pointer / size");
+  g_ws[dev] = GemmWorkspace{ptr, (long)bytes};
+  return HI3D_OK;
+}
 
 extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->out) HI3D_FAIL(HI3D_EINVAL, "gemm: null pointer");
@@ -895,6 +959,24 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     variant = 8;
   }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
+  // split-K: a long-K launch that leaves most of the chip's 512 block slots (256 CUs x 2 blocks of the 128-row tile) empty
+  // -- M = 1-4 K rows: the 8x8 level of stage 1 ran at 370 TFLOP/s, every level does on the ranks of a clip-parallel job --
+  // is cut along K into `ksplit` blocks per tile in ONE grid; fp32 partial tiles go to the caller's workspace
+  // (hi3d_gemm_set_workspace) and splitk_combine_kernel applies the epilogue.  HI3D_GEMM_SPLITK=0 disables, =S forces S.
+  int ksplit = 1;
+  if ((variant == 0 || variant == 2) && (tile == 128 || tile == 160) && d->epi == HI3D_EPI_AFFINE && d->K >= 2048 &&
+      (long)d->M * d->N >= (1L << 18) && (((uintptr_t)d->out | (uintptr_t)d->R1 | (uintptr_t)d->R2) & 7) == 0) {
+    int dev = -1;
+    static const int force = [] { const char* e = getenv("HI3D_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+    if (force != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < HI3D_MAX_DEVICES && g_ws[dev].ptr) {
+      const int taps = d->amode == HI3D_A_CONV3X3 ? 9 : d->amode == HI3D_A_CONVT3 ? 3 : 1;
+      const int units = d->K / BK / taps;
+      const long part = (long)d->M * d->N * 4, tiles = (long)((d->M + 127) / 128) * ((d->N + tile - 1) / tile);
+      ksplit = splitk_choose(tiles, units, taps, part, g_ws[dev].bytes);
+      if (force > 1 && units % force == 0 && part * force <= g_ws[dev].bytes) ksplit = force;
+      if (ksplit > 1) variant = 0;                 // (the 256-row tile of variant 2 would halve the tile count again)
+    }
+  }
   if (variant == 5 || variant == 7) tile = 320;   // 256 x 320 tile: 8 waves of 64 x 160, one block per CU
   if (variant == 8) tile = 256;                   // 256 x 256 tile: 8 waves of 64 x 128
   const int bm = (variant == 2 || variant >= 5) ? 256 : 128;
@@ -914,6 +996,23 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (const char* e = getenv("HI3D_GEMM_GN")) p.gn = atoi(e);
   }
   hipStream_t s = (hipStream_t)stream;
+  p.ksplit = 1; p.nk_split = d->K / BK;
+  if (ksplit > 1) {
+    int dev = -1;
+    hipGetDevice(&dev);
+    GemmParams q = p;
+    q.ksplit = ksplit; q.nk_split = d->K / BK / ksplit;
+    q.out = g_ws[dev].ptr; q.out_fp32 = 1; q.ldo = d->N; q.vec8 = d->N % 8 == 0;
+    q.bias = nullptr; q.rowvec = nullptr; q.R1 = nullptr; q.R2 = nullptr; q.a1 = nullptr; q.a2 = nullptr;
+    const int rc = tile == 160 ? dispatch<2, 5, 2>(q, d->amode, d->epi, s) : dispatch<2, 4, 2>(q, d->amode, d->epi, s);
+    if (rc || g_capture) return rc;
+    CombineParams c{(const float*)g_ws[dev].ptr, d->bias, d->rowvec, (const unsigned short*)d->R1, (const unsigned short*)d->R2,
+                    d->a1, d->a2, d->out, d->M, d->N, ksplit, d->ldo, d->ldr1, d->ldr2, p.ldrv, d->rows_per_group, d->out_fp32};
+    const long nthr = (long)d->M * (d->N / 4);
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, c);
+    HI3D_LAUNCH_CHECK();
+    return HI3D_OK;
+  }
   if (tile == 256) return dispatch<4, 8, 2, true>(p, d->amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);
   if (tile == 32) {

@@ -3,6 +3,8 @@ current HIP stream, every FLOP runs in libhi3d_hip.so.
 
 Activations: torch.bfloat16, channels-last tokens [frames, H*W, C] (contiguous).
 """
+import os
+
 import torch
 
 from . import lib as _l
@@ -109,6 +111,25 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
     return d, out
 
 
+_GEMM_WS = {}        # device index -> the split-K scratch registered with the library (held for the life of the process)
+
+
+def _ensure_gemm_workspace(dev):
+    """Register hi3d_gemm_bf16's split-K scratch on `dev` once (HI3D_GEMM_WS_MB, default 96 MiB = 8 partial tiles of the
+    largest launch that is ever split; 0 = none).  Not during a graph capture: the allocation would belong to the capture's
+    pool -- the eager steps that precede every capture in this package have registered it by then."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _GEMM_WS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    mb = int(os.environ.get("HI3D_GEMM_WS_MB", "96"))
+    ws = torch.empty(mb << 20, dtype=torch.uint8, device=dev) if mb > 0 else None
+    with torch.cuda.device(idx):
+        _l.check(_lib.hi3d_gemm_set_workspace(_p(ws), mb << 20 if ws is not None else 0), "hi3d_gemm_set_workspace")
+    _GEMM_WS[idx] = ws
+
+
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
          lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
@@ -118,6 +139,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     """
     d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
                        a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n)
+    _ensure_gemm_workspace(A.device)
     n_out = N // 2 if geglu else N
     prof = PROFILER
     t0 = prof.begin() if prof else None

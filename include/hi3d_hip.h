@@ -105,6 +105,13 @@ typedef struct hi3d_gemm_desc {
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
+/* Scratch for split-K (optional; per device: call with that device current).  Long-K launches whose M x N gives the chip too
+ * few tiles -- the 8x8 / 16x16 levels (openaimodel.py:ResBlock convs at ds = 8, video_model.py:VideoResBlock time_stack),
+ * every level on the ranks of a clip-parallel job -- are cut along K inside ONE grid; the fp32 partial tiles
+ * ([S][M][N], S <= 8) go here and a second kernel sums them in a fixed order and applies the epilogue.  `bytes` bounds
+ * S * M * N * 4; ptr = NULL / bytes = 0 withdraws the workspace (no split-K: same results up to fp32 summation order).  The
+ * buffer must outlive every hi3d_gemm_bf16 call on the device and is used by one stream at a time. */
+int hi3d_gemm_set_workspace(void* ptr, int64_t bytes);
 /* debug aid (ISA-level timing stress, hi3d_hip/devtools/isa_stress.py): the launch hi3d_gemm_bf16(d) WOULD make, not made.
  * params_out (>= 512 bytes) <- the kernel argument; info[10] <- {its size, grid, block, dynamic LDS bytes, and the template
  * arguments WM, NT, NS, AMODE, EPI, PP of the gemm_bf16_kernel instantiation}.                                              */

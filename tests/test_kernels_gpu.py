@@ -242,6 +242,83 @@ def test_conv_temporal(dev, B, T, HW, C):
     assert relerr(got, ref) < BF16_TOL
 
 
+def _splits(ops, desc):
+    """K splits of the launch hi3d_gemm_bf16 would make for `desc` (grid / tiles of the 128-row tile it reports)."""
+    import ctypes as C
+    from hi3d_hip import lib as L
+    buf, info = C.create_string_buffer(512), (C.c_int32 * 10)()
+    L.check(L.load().hi3d_debug_gemm_launch_info(C.byref(desc), buf, info), "hi3d_debug_gemm_launch_info")
+    grid, WM, NT = info[1], info[4], info[5]
+    tiles = -(-desc.M // (64 * WM)) * -(-desc.N // (32 * NT))
+    assert grid % tiles == 0
+    return grid // tiles
+
+
+@pytest.mark.parametrize("kind", ["dense", "conv3x3", "conv3x3_up2x", "conv3x3_stride2", "convt3"])
+def test_gemm_split_k(dev, kind):
+    """Long-K launches with too few tiles for the chip are cut along K inside one grid (fp32 partial tiles in the registered
+    workspace + splitk_combine_kernel): every A-gather mode with the FULL epilogue (bias, per-group row vector, both
+    residuals, both blend factors) against fp32, against the unsplit launch (workspace withdrawn), and repeatable bit for bit.
+    The shapes are chosen so that the library's own heuristic splits them (checked through the launch it reports)."""
+    import ctypes as C
+    from hi3d_hip import lib as L, ops
+    from hi3d_hip.pack import pack_conv3x3, pack_convt3
+    kw, conv = {}, None
+    if kind == "dense":
+        M, N, K = 640, 512, 2048
+        A, Wm = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, K ** -0.5))
+        acc = A.float() @ Wm.float().T
+    elif kind.startswith("conv3x3"):
+        up, stride = int(kind.endswith("up2x")), 2 if kind.endswith("stride2") else 1
+        Fr, H, W_, Cin, N = (4, 8, 8, 256, 320) if up else (4, 32, 32, 256, 320) if stride == 2 else (4, 16, 16, 256, 320)
+        x = bf(rnd((Fr, Cin, H, W_), 1))
+        w = bf(rnd((N, Cin, 3, 3), 2, (9 * Cin) ** -0.5)).float()
+        xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+        r = F.conv2d(xin, w, None, stride=stride, padding=1)
+        Ho, Wo = r.shape[-2:]
+        acc = r.permute(0, 2, 3, 1).reshape(-1, N)
+        A, Wm = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin), pack_conv3x3(w, Cin)
+        M, K = Fr * Ho * Wo, 9 * Cin
+        kw = dict(conv3x3=dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, up2x=up))
+    else:
+        B, T, HW, Cc, N = 1, 8, 128, 768, 768
+        x = bf(rnd((B, Cc, T, HW, 1), 1))
+        w = bf(rnd((N, Cc, 3, 1, 1), 2, (3 * Cc) ** -0.5)).float()
+        acc = F.conv3d(x.float(), w, None, padding=(1, 0, 0)).squeeze(-1).permute(0, 2, 3, 1).reshape(-1, N)
+        A, Wm = x.squeeze(-1).permute(0, 2, 3, 1).contiguous().reshape(-1, Cc), pack_convt3(w)
+        M, K = B * T * HW, 3 * Cc
+        kw = dict(convt3=dict(T=T, HW=HW, Cin=Cc))
+    rpg = 128
+    G = M // rpg
+    bias, rowvec = rnd((N,), 3), rnd((G, N), 4)
+    R1, R2 = bf(rnd((M, N), 5)), bf(rnd((M, N), 6))
+    a1, a2 = rnd((G,), 7).abs() + 0.5, rnd((G,), 8)
+    grp = torch.arange(M) // rpg
+    ref = (acc + bias + rowvec[grp] + R1.float()) * a1[grp, None] + a2[grp, None] * R2.float()
+    args = dict(M=M, N=N, K=K, bias=bias.to(dev), rowvec=rowvec.to(dev), rows_per_group=rpg, R1=R1.to(dev), R2=R2.to(dev),
+                a1=a1.to(dev), a2=a2.to(dev), **kw)
+    Ad, Wd = A.to(dev), Wm.to(dev)
+    out = ops.gemm(Ad, Wd, **args)                                     # (registers the workspace on first use)
+    S = _splits(ops, ops.gemm_desc(Ad, Wd, **args)[0])
+    print(f"{kind}: M={M} N={N} K={K} -> {S} K splits")
+    assert S >= 2, "the heuristic was expected to split this launch"
+    assert relerr(out, ref) < BF16_TOL
+    for _ in range(20):
+        assert torch.equal(ops.gemm(Ad, Wd, **args), out)
+    out32 = ops.gemm(Ad, Wd, M=M, N=N, K=K, bias=bias.to(dev), out_fp32=True, **kw)
+    assert relerr(out32, acc + bias) < 2e-5
+    lib = L.load()
+    ws = ops._GEMM_WS[dev.index or 0]
+    try:
+        L.check(lib.hi3d_gemm_set_workspace(None, 0), "hi3d_gemm_set_workspace")
+        assert _splits(ops, ops.gemm_desc(Ad, Wd, **args)[0]) == 1
+        plain = ops.gemm(Ad, Wd, **args)
+    finally:
+        L.check(lib.hi3d_gemm_set_workspace(C.c_void_p(ws.data_ptr()), ws.numel()), "hi3d_gemm_set_workspace")
+    assert relerr(plain, ref) < BF16_TOL
+    assert relerr(out, plain.float().cpu()) < 8e-3                      # same math, different fp32 summation order + one bf16 rounding
+
+
 @pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 2, 16), (1, 1, 4), (1, 3, 129)])
 def test_attention_d64(dev, B, H, S):
     from hi3d_hip import ops
