@@ -5,7 +5,7 @@ pmc_traffic.py summaries of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pas
 usage: make_traffic_json.py FETCH.csv WRITE.csv out.json
 
 FETCH_SIZE is doubled: on gfx950 it counts half of the bytes of 16 B/lane streams (see
-MI355X_MICROARCH.md; calibrated here on layernorm_kernel<1>, which reads 327,680 KB per launch at the
+MI355X_MICROARCH.md; calibrated here on the C = 320 LayerNorm kernel, which reads 327,680 KB per launch at the
 128^2 level and reports 163,9xx KB).  Both counters are in KB."""
 import csv
 import json
@@ -30,7 +30,7 @@ def family(rows, prefix):
 def main():
     fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
     res = {}
-    for fam in ("gemm_bf16_kernel", "attn_d64_kernel", "ffn_geglu_c320_kernel"):
+    for fam in ("gemm_bf16_kernel", "attn_d64_kernel", "ffn2_geglu_c320_kernel"):
         nf, sf = family(fetch, fam)
         nw, sw = family(write, fam)
         n = max(nf, nw)
@@ -43,9 +43,10 @@ def main():
             "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
                       "FETCH_SIZE doubled (gfx950 half-count for 16 B/lane streams, calibrated on layernorm)",
         }
-    cal = fetch.get("layernorm_kernel<1>")
+    # calibration: the C = 320 LayerNorm reads 524288 x 320 bf16 = 327,680 KB per launch at the 128^2 level
+    cal = [v for k, v in fetch.items() if k.startswith("layernorm_packed_kernel<8>") or k.startswith("layernorm_kernel<1>")]
     if cal:
-        res["calibration"] = {"layernorm_kernel<1>_fetch_KB_per_launch_reported": cal[1] / cal[0],
+        res["calibration"] = {"layernorm_C320_fetch_KB_per_launch_reported": sum(c[1] for c in cal) / sum(c[0] for c in cal),
                               "bytes_actually_read_KB": 327680}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -1,40 +1,37 @@
 #!/bin/bash
 # Regenerates what profiles/ holds for a round, on the GPU box (run through gpurun from the repo root):
-#   bench lines + per-shape logs (stage 2 with CPU baseline, stage 1, VAE decode, fp8-QK attention variant),
+#   the default bench line (headline + every leg of BASELINE.json's configurations from one run) with the per-shape log,
 #   rocprofv3 kernel-trace summary of the stage-2 bench, and PMC passes (separate runs, kernel trace only, as the
 #   pool requires): FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel) and two SQ passes (MFMA busy / VALU).
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ (tools/collect_profiles.sh).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py --config s2 --steps 10 --warmup 3 --shapes > $O/s2_bench.json 2> $O/s2_bench.log
-python bench.py --config s1 --steps 20 --warmup 3 --shapes --no-cpu-baseline > $O/s1_bench.json 2> $O/s1_bench.log
-python bench.py --config vae --steps 2 --warmup 1 > $O/vae_bench.json 2> $O/vae_bench.log
-python bench.py --config s2 --attn fp8qk --steps 6 --warmup 3 --no-cpu-baseline > $O/s2_fp8qk_bench.json 2> $O/s2_fp8qk_bench.log
+python bench.py --steps 10 --warmup 3 --shapes > $O/s2_bench.json 2> $O/s2_bench.log        # (legs: s1, 32 views, fp8qk, fp8, VAE, simulated rank)
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile > $O/s2_bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile --no-legs > $O/s2_bench_under_rocprof.log 2>&1
 DB=$(ls /tmp/prof_kt/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats.csv 2> $O/s2_kernel_stats.txt
 rm -rf /tmp/prof_kt
 rocprofv3 -L > $O/rocprof_counters.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_$c.log 2>&1
+  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-legs > $O/pmc_$c.log 2>&1
   python $R/tools/pmc_traffic.py /tmp/pmc_$c $c > $O/s2_pmc_$c.csv
   rm -rf /tmp/pmc_$c
 done
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_sq$i -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $O/pmc_sq$i.log 2>&1
+  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_sq$i -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-legs > $O/pmc_sq$i.log 2>&1
   python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.csv 2>&1
   rm -rf /tmp/pmc_sq$i
 done
 if [ -n "$LIGHT" ]; then     # (the per-shape conv traffic and the GEMM variant sweep only change when gemm.hip does)
-  cat $O/s2_bench.json | cut -c1-900; cat $O/s1_bench.json | cut -c1-300; cat $O/vae_bench.json | cut -c1-400
-  cat $O/s2_fp8qk_bench.json | cut -c1-300; head -14 $O/s2_kernel_stats.csv; head -8 $O/s2_pmc_FETCH_SIZE.csv
+  python $R/tools/make_traffic_json.py $O/s2_pmc_FETCH_SIZE.csv $O/s2_pmc_WRITE_SIZE.csv $O/traffic_s2.json
+  cat $O/s2_bench.json | cut -c1-900; head -14 $O/s2_kernel_stats.csv; head -8 $O/s2_pmc_FETCH_SIZE.csv
   head -8 $O/s2_pmc_WRITE_SIZE.csv; head -14 $O/s2_pmc_sq1.csv; head -8 $O/s2_pmc_sq2.csv
   exit 0
 fi
@@ -55,9 +52,6 @@ cat $O/conv_traffic_per_shape.txt
 cd $R; python tools/kbench.py sweep h 0 5 7 > $O/gemm_variant_sweep.log 2>&1; cd /tmp
 grep "geglu" $O/gemm_variant_sweep.log
 cat $O/s2_bench.json | cut -c1-700
-cat $O/s1_bench.json | cut -c1-300
-cat $O/vae_bench.json | cut -c1-400
-cat $O/s2_fp8qk_bench.json | cut -c1-300
 head -12 $O/s2_kernel_stats.csv
 head -8 $O/s2_pmc_FETCH_SIZE.csv
 head -8 $O/s2_pmc_WRITE_SIZE.csv
