@@ -344,7 +344,7 @@ template <int TP>
 __global__ __launch_bounds__(256) void attn_temporal_kernel(
     const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
     const unsigned short* __restrict__ v, unsigned short* __restrict__ out,
-    int T, int S, int ld, int ldo, float scale_log2) {
+    int T, int S, int ld, int ldo, float scale_log2, int hfast) {
   constexpr int PB = 256 / TP;
   constexpr int KPIX = TP * 128 + 16;            // bytes of keys per pixel (+16: spreads pixels over banks)
   constexpr int VROW = TP * 2;                   // bytes per (pixel, d) row of V^T
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
   __shared__ __attribute__((aligned(16))) char sK[PB * KPIX];
   __shared__ __attribute__((aligned(16))) char sV[PB * VPIX];
   const int tid = threadIdx.x;
-  const int s0 = blockIdx.x * PB, h = blockIdx.y, b = blockIdx.z;
+  // hfast: heads on the fastest grid axis -- the blocks in flight at one time then read ALL heads' 128-byte pieces of the
+  // same token rows (one contiguous 3C-wide row per pixel and frame) instead of one piece out of every row
+  const int s0 = (hfast ? blockIdx.y : blockIdx.x) * PB, h = hfast ? blockIdx.x : blockIdx.y, b = blockIdx.z;
 
   // ---- stage K rows and transposed V: 8 chunks of 16 B per (pixel, frame).  PB * TP * 8 / 256 = 8 chunks per
   // thread: all 16 loads are issued before the first LDS write (the rolled loop had two loads in flight per thread
@@ -371,6 +373,19 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
       vq[i] = *(const uint4*)(v + off);
     }
   }
+  // this thread's query row is requested now, with the K / V loads still in flight (it used to be loaded after the barrier,
+  // a second exposed HBM round trip per block)
+  const int tq = tid % TP, px = tid / TP;
+  const bool active = tq < T && s0 + px < S;
+  unsigned int qr[32];
+  {
+    const long qoff = (((long)b * T + (active ? tq : 0)) * S + (active ? s0 + px : s0)) * ld + h * 64;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint4 t4 = *(const uint4*)(q + qoff + c * 8);
+      qr[c * 4] = t4.x; qr[c * 4 + 1] = t4.y; qr[c * 4 + 2] = t4.z; qr[c * 4 + 3] = t4.w;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * 256;
@@ -386,15 +401,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
   }
   __syncthreads();
 
-  const int tq = tid % TP, px = tid / TP;
-  if (tq >= T || s0 + px >= S) return;
-  const long qoff = (((long)b * T + tq) * S + s0 + px) * ld + h * 64;
-  unsigned int qr[32];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint4 t4 = *(const uint4*)(q + qoff + c * 8);
-    qr[c * 4] = t4.x; qr[c * 4 + 1] = t4.y; qr[c * 4 + 2] = t4.z; qr[c * 4 + 3] = t4.w;
-  }
+  if (!active) return;
   float sc[TP];
   float mx = -INFINITY;
 #pragma unroll
@@ -499,18 +506,20 @@ extern "C" int hi3d_attn_temporal_d64(const void* q, const void* k, const void* 
   if (H > 65535 || B > 65535) HI3D_FAIL(HI3D_ESHAPE, "attn_temporal: grid too large");
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  static const int hfast_env = [] { const char* e = getenv("HI3D_ATTNT_HFAST"); return e ? atoi(e) : 1; }();
+  const int hfast = (hfast_env && (S + 7) / 8 <= 65535) ? 1 : 0;
   if (T <= 8) {
     constexpr int TP = 8, PB = 256 / TP;
-    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
-                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, hfast ? dim3(H, (S + PB - 1) / PB, B) : dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2, hfast);
   } else if (T <= 16) {
     constexpr int TP = 16, PB = 256 / TP;
-    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
-                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, hfast ? dim3(H, (S + PB - 1) / PB, B) : dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2, hfast);
   } else {
     constexpr int TP = 32, PB = 256 / TP;
-    hipLaunchKernelGGL(attn_temporal_kernel<TP>, dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
-                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2);
+    hipLaunchKernelGGL(attn_temporal_kernel<TP>, hfast ? dim3(H, (S + PB - 1) / PB, B) : dim3((S + PB - 1) / PB, H, B), dim3(256), 0, s,
+                       (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out, T, S, ldqkv, ldo, sl2, hfast);
   }
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
