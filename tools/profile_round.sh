@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py --steps 10 --warmup 3 --shapes > $O/s2_bench.json 2> $O/s2_bench.log        # (legs: s1, 32 views, fp8qk, fp8, VAE, simulated rank)
+python bench.py --gpus 1 --steps 20 --warmup 5 --shapes > $O/s2_bench.json 2> $O/s2_bench.log        # (legs: s1, 32 views, fp8qk, fp8, VAE, simulated rank)
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile --no-legs > $O/s2_bench_under_rocprof.log 2>&1
