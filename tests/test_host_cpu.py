@@ -422,3 +422,42 @@ def test_torch_library_ops_are_registered_and_refuse_cpu_tensors():
         ns.self_attention(torch.zeros(4, 192, dtype=torch.bfloat16), 1, 4, 1, 0.125)
     with pytest.raises((NotImplementedError, RuntimeError)):
         ns.layernorm(torch.zeros(4, 320, dtype=torch.bfloat16), torch.ones(320), torch.zeros(320), 1e-5)
+
+
+def test_conditioner_runs_each_embedder_once_for_c_and_uc():
+    """get_unconditional_conditioning on ONE batch (both Hi3D pipelines): every embedder is evaluated once, c and uc are
+    what two separate passes give (reference encoders/modules.py:143-156), the forced keys are zero in uc, and the two
+    dicts share no storage.  A separate uc batch still takes two passes."""
+    import torch
+    from sgm.modules.encoders.modules import GeneralConditioner
+
+    class Stub(torch.nn.Module):
+        def __init__(self, key, dim, scale):
+            super().__init__()
+            self.input_key, self.dim, self.scale, self.calls = key, dim, scale, 0
+
+        def forward(self, x):
+            self.calls += 1
+            flat = x.reshape(x.shape[0], -1)[:, :6].float() * self.scale
+            return {2: flat, 3: flat[:, None, :], 4: flat.reshape(x.shape[0], 6, 1, 1)}[self.dim]
+
+    cond = GeneralConditioner([])
+    stubs = [Stub("cond_frames_without_noise", 3, 1.0), Stub("elevation", 2, 2.0), Stub("cond_aug", 2, 3.0),
+             Stub("cond_frames", 4, 4.0), Stub("cond_frames", 4, 5.0)]
+    cond.embedders = torch.nn.ModuleList(stubs)
+    g = torch.Generator().manual_seed(0)
+    batch = {k: torch.randn((2, 8), generator=g) for k in ("cond_frames_without_noise", "elevation", "cond_aug", "cond_frames")}
+    force = ["cond_frames", "cond_frames_without_noise"]
+    c, uc = cond.get_unconditional_conditioning(batch, force_uc_zero_embeddings=force)
+    assert [s_.calls for s_ in stubs] == [1] * 5
+    c2, uc2 = cond(batch), cond(batch, force)
+    for k in ("crossattn", "vector", "concat"):
+        assert torch.equal(c[k], c2[k]) and torch.equal(uc[k], uc2[k])
+        assert c[k].data_ptr() != uc[k].data_ptr()
+    assert float(uc["crossattn"].abs().max()) == 0.0 and float(uc["concat"].abs().max()) == 0.0
+    assert torch.equal(uc["vector"], c["vector"]) and c["vector"].shape == (2, 12) and c["concat"].shape == (2, 12, 1, 1)
+    other = {k: v + 1 for k, v in batch.items()}
+    before = [s_.calls for s_ in stubs]
+    c3, uc3 = cond.get_unconditional_conditioning(batch, other, force)
+    assert [s_.calls for s_ in stubs] == [b + 2 for b in before]
+    assert torch.equal(c3["vector"], c["vector"]) and not torch.equal(uc3["vector"], c["vector"])
