@@ -305,6 +305,9 @@ def main():
         # bf16 error accumulation over the whole 25-step schedule at full width (~4 min)
         jobs["sampler_s1_w320_25step"] = lambda: gen_sampler("sampler_s1_w320_25step", unet_cfg(1), T=4, hw=16, steps=25,
                                                              max_scale=2.5, stage=1, iseed=9)
+        # the stage-2 refine loop (re-noising blend + Euler-EDM + CFG, pipeline_i2v_eval_v02.py:103-135) over its whole
+        # 25-step schedule at full width, 17 input channels (~5 min)
+        jobs["v02_w320_25step"] = lambda: gen_v02("v02_w320_25step", unet_cfg(2), T=4, hw=16, steps=25, max_scale=2.0, iseed=11)
         # decode_first_stage of one frame at the two shipped resolutions, full-width decoder
         jobs["vae_full_512"] = lambda: gen_vae("vae_full_512", 128, 1, 64, iseed=5, compact=True)
         jobs["vae_full_1024"] = lambda: gen_vae("vae_full_1024", 128, 1, 128, iseed=6, compact=True)

@@ -273,6 +273,36 @@ def test_sampler_25_steps_full_width_matches_reference_golden(dev):
     assert num_sigmas - 1 == 25 and cos(x, fx["output"]) > 0.999
 
 
+def test_stage2_refine_25_steps_full_width_matches_reference_golden(dev):
+    """The north-star loop itself over its whole schedule: pipeline_i2v_eval_v02.py:103-135 -- re-noising blend towards the
+    stage-1 latents, Euler-EDM, CFG 1 -> 2.0 -- for 25 steps through the full-width (1.52 B parameters, 17 input channels)
+    stage-2 UNet, hi3d_hip.pipelines.stage2_refine (fused blend kernel + fused graph-replayed step) vs the reference's
+    own loop run with the reference classes (oracle/gen_golden.py:gen_v02).  Final latents: cosine >= 0.999, max-abs
+    error <= 6e-2 x max-abs reference (the sampler tolerance of DESIGN.md section 5)."""
+    from types import SimpleNamespace
+    from hi3d_hip.pipelines import stage2_refine
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    fx = load("v02_w320_25step")
+    T = fx["T"]
+    model = SimpleNamespace(
+        device=dev, model=OpenAIWrapper(_build_unet(fx, dev)),
+        denoiser=Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
+        sampler=EulerEDMSampler(
+            num_steps=fx["steps"], device=dev,
+            discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+            guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                           "params": {"num_frames": T, "max_scale": fx["max_scale"], "min_scale": 1.0}}))
+    c = {k: v.to(dev) for k, v in fx["c"].items()}
+    uc = {k: v.to(dev) for k, v in fx["uc"].items()}
+    out = stage2_refine(model, None, c, uc, init_noise=fx["init"], decode=False, z_frames=fx["z_frames"])
+    rel, cs = relerr(out, fx["output"]), cos(out, fx["output"])
+    print(f"stage-2 refine, 25 steps, full width: rel {rel:.4f} cos {cs:.6f}")
+    assert fx["steps"] == 25 and fx["cfg"]["in_channels"] == 17 and fx["cfg"]["model_channels"] == 320
+    assert rel < 6e-2 and cs > 0.999
+
+
 @pytest.mark.parametrize("name", ["vae_full_512", "vae_full_1024"])
 def test_vae_decode_full_resolution_matches_reference_golden(dev, name):
     """decode_first_stage of one frame at 512x512 / 1024x1024 through the full-width decoder (16384-token

@@ -103,6 +103,7 @@ def test_vae_encode_oracle_matches_reference(name):
 
 
 def test_v02_refine_oracle_matches_reference():
+    """(the full-width 25-step golden v02_w320_25step is consumed by the GPU suite only: the oracle needs minutes for it)"""
     fx = load("v02_tiny")
     with torch.no_grad():
         out = O.v02_refine(weights(fx), fx["cfg"], fx["z_frames"], fx["init"], fx["c"], fx["uc"], fx["T"], fx["steps"],
