@@ -146,7 +146,8 @@ def gen_vae(name, ch, n, hw, wseed=1, iseed=0, compact=False):
     print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
 
-def gen_vae_encode(name, ch, n, hw, wseed=1, iseed=0):
+def gen_vae_encode(name, ch, n, hw, wseed=1, iseed=0, compact=False):
+    """compact: x is re-drawn from `input_seed` by the test (pinned by `x_head`)."""
     t0 = time.time()
     AE = ref_import.ref("sgm.models.autoencoder.AutoencoderKL")
     dd = vae_ddconfig(ch)
@@ -165,6 +166,8 @@ def gen_vae_encode(name, ch, n, hw, wseed=1, iseed=0):
     fx = dict(kind="vae_encode", ddconfig=dd, weight_seed=wseed, key_prefix=VAE_PREFIX, x=x, moments=moments,
               z_sampled=z_sampled, sample_noise=ref_noise, noise=noise,
               shapes={k: tuple(v.shape) for k, v in sd.items()})
+    if compact:
+        fx.update(x=None, input_seed=iseed, x_shape=tuple(x.shape), x_head=x.flatten()[:16].clone())
     torch.save(fx, os.path.join(GOLD, name + ".pt"))
     print(f"{name}: moments {tuple(moments.shape)} absmax {moments.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
@@ -309,6 +312,8 @@ def main():
         # 25-step schedule at full width, 17 input channels (~5 min)
         jobs["v02_w320_25step"] = lambda: gen_v02("v02_w320_25step", unet_cfg(2), T=4, hw=16, steps=25, max_scale=2.0, iseed=11)
         # decode_first_stage of one frame at the two shipped resolutions, full-width decoder
+        # encode_first_stage of one frame at the stage-2 resolution, full-width encoder (16384-token mid-block attention)
+        jobs["vae_enc_full_1024"] = lambda: gen_vae_encode("vae_enc_full_1024", 128, 1, 1024, iseed=12, compact=True)
         jobs["vae_full_512"] = lambda: gen_vae("vae_full_512", 128, 1, 64, iseed=5, compact=True)
         jobs["vae_full_1024"] = lambda: gen_vae("vae_full_1024", 128, 1, 128, iseed=6, compact=True)
         jobs["unet_s2_full"] = lambda: gen_unet("unet_s2_full", unet_cfg(2), T=16, hw=128, iseed=8, compact=True)

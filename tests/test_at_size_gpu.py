@@ -303,6 +303,28 @@ def test_stage2_refine_25_steps_full_width_matches_reference_golden(dev):
     assert rel < 6e-2 and cs > 0.999
 
 
+def test_vae_encode_full_resolution_matches_reference_golden(dev):
+    """encode_first_stage of one 1024 x 1024 frame through the full-width encoder (what stage 2 does 16 times per clip for
+    the refine loop and 16 times for the conditioning latents): bottom/right-padded stride-2 convs from 1 M pixels down,
+    16384-token d = 512 mid-block attention, quant_conv, posterior -- mode vs the reference's mean, sample (with the
+    reference's own CPU noise draw) vs its posterior.sample()."""
+    from hi3d_hip import synth
+    from sgm.models.autoencoder import AutoencoderKL
+    fx = load("vae_enc_full_1024")
+    g = torch.Generator().manual_seed(fx["input_seed"])
+    x = torch.rand(fx["x_shape"], generator=g) * 2 - 1
+    assert torch.equal(x.flatten()[:16], fx["x_head"]), "input re-draw does not reproduce the generator's"
+    ae = AutoencoderKL(embed_dim=4, ddconfig=fx["ddconfig"])
+    synth.fill_module_(ae, fx["weight_seed"], prefix=fx["key_prefix"])
+    ae = ae.to(dev)
+    z = ae.encode(x.to(dev), noise=fx["sample_noise"]).float().cpu()
+    zm = ae.encode(x.to(dev), noise=torch.zeros_like(fx["sample_noise"])).float().cpu()      # mean: sample with zero noise
+    mean_ref = fx["moments"][:, :4]
+    rel_s, rel_m = relerr(z, fx["z_sampled"]), relerr(zm, mean_ref)
+    print(f"vae encode 1024^2: sample rel {rel_s:.4f} cos {cos(z, fx['z_sampled']):.6f}  mean rel {rel_m:.4f}")
+    assert tuple(z.shape) == (1, 4, 128, 128) and rel_s < 4e-2 and rel_m < 4e-2 and cos(z, fx["z_sampled"]) > 0.9995
+
+
 @pytest.mark.parametrize("name", ["vae_full_512", "vae_full_1024"])
 def test_vae_decode_full_resolution_matches_reference_golden(dev, name):
     """decode_first_stage of one frame at 512x512 / 1024x1024 through the full-width decoder (16384-token
