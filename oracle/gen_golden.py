@@ -312,6 +312,11 @@ def main():
         # 25-step schedule at full width, 17 input channels (~5 min)
         jobs["v02_w320_25step"] = lambda: gen_v02("v02_w320_25step", unet_cfg(2), T=4, hw=16, steps=25, max_scale=2.0, iseed=11)
         # decode_first_stage of one frame at the two shipped resolutions, full-width decoder
+        # BASELINE config 4's frame count through the full-width stage-2 UNet: temporal attention / Conv3d / 3-D GroupNorm over
+        # 32 frames at every width (latent 16 x 16 so the reference finishes in about a minute)
+        jobs["unet_s2_lat16_t32"] = lambda: gen_unet("unet_s2_lat16_t32", unet_cfg(2), T=32, hw=16, iseed=77, compact=True)
+        # the temporal VideoDecoder (time_mode conv-only) at full width on a 4-frame clip of 256 x 256
+        jobs["videodec_full_lat32"] = lambda: gen_video_decode("videodec_full_lat32", 128, 1, 4, 32, iseed=13)
         # encode_first_stage of one frame at the stage-2 resolution, full-width encoder (16384-token mid-block attention)
         jobs["vae_enc_full_1024"] = lambda: gen_vae_encode("vae_enc_full_1024", 128, 1, 1024, iseed=12, compact=True)
         jobs["vae_full_512"] = lambda: gen_vae("vae_full_512", 128, 1, 64, iseed=5, compact=True)

@@ -102,6 +102,18 @@ def test_vae_encode_oracle_matches_reference(name):
     assert rel(z, fx["z_sampled"]) < TOL          # reference posterior.sample() with the same CPU draw
 
 
+def test_unet_oracle_matches_reference_at_32_views_full_width():
+    """The oracle at BASELINE config 4's frame count: full-width stage-2 UNet, T = 32, latent 16 x 16, against one forward of
+    the reference VideoUNet (golden stored in fp16: 5e-4 of quantisation, hence the looser bound)."""
+    fx = load("unet_s2_lat16_t32")
+    inp = synth.synth_unet_inputs(fx["cfg"], fx["T"], fx["hw"], fx["input_seed"])
+    assert torch.equal(inp["x"].flatten()[:16], fx["input_probe"]["head"])
+    with torch.no_grad():
+        out = O.video_unet(weights(fx), fx["cfg"], inp["x"], inp["timesteps"], inp["context"], inp["y"], fx["T"],
+                           inp["image_only_indicator"], prefix=fx["key_prefix"])
+    assert fx["T"] == 32 and rel(out, fx["output"].float()) < 1e-3
+
+
 def test_v02_refine_oracle_matches_reference():
     """(the full-width 25-step golden v02_w320_25step is consumed by the GPU suite only: the oracle needs minutes for it)"""
     fx = load("v02_tiny")
@@ -111,7 +123,7 @@ def test_v02_refine_oracle_matches_reference():
     assert rel(out, fx["output"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8"])
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32"])
 def test_video_decoder_oracle_matches_reference(name):
     fx = load(name)
     with torch.no_grad():

@@ -109,7 +109,7 @@ def test_conv3x3_bottom_right_padding(dev):
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1.2e-2
 
 
-@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8"])
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32"])
 def test_video_decoder_matches_reference_golden(dev, name):
     """Temporal VAE decoder (north_star's 'AutoencoderKLTemporalDecoder' = VideoDecoder) through
     AutoencodingEngine + the DiffusionEngine.decode_first_stage `timesteps` hook."""
