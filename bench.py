@@ -59,6 +59,29 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def guard_line(line):
+    """Insurance for the ONE JSON line while an optional leg runs that could take the process down hard (a collective library
+    aborting cannot be caught in Python): a detached helper that inherits stdout blocks on a pipe whose write end only THIS
+    process holds.  disarm() sends it a byte (the normal path: the caller prints the complete line itself); if the process
+    dies instead, the helper sees end-of-file and prints `line`."""
+    import subprocess
+    r, w = os.pipe()
+    code = ("import os,sys\n"
+            "b=os.read(int(sys.argv[1]),1)\n"
+            "if b==b'':\n    sys.stdout.write(sys.argv[2]+'\\n'); sys.stdout.flush()\n")
+    subprocess.Popen([sys.executable, "-c", code, str(r), line], stdin=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                     start_new_session=True, pass_fds=(r,))
+    os.close(r)
+    state = {"armed": True}
+
+    def disarm():
+        if state["armed"]:
+            state["armed"] = False
+            os.write(w, b"x")
+            os.close(w)
+    return disarm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,10 +150,14 @@ def main():
         import threading
 
         def _bail():
+            disarm()
             if rank == 0:
                 out["clip_parallel"] = {"error": "timed out (watchdog); headline numbers above are unaffected"}
                 print(json.dumps(out), flush=True)
             os._exit(0)
+        # ... and if the process itself dies in there (an abort inside the collective library), a detached helper prints it
+        disarm = guard_line(json.dumps(dict(out, clip_parallel={"error": "process died inside the optional leg; headline numbers "
+                                                                         "above are unaffected"}))) if rank == 0 else (lambda: None)
         wd = threading.Timer(max(90.0, 40.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
         wd.daemon = True
         wd.start()
@@ -139,6 +166,7 @@ def main():
         except Exception as e:
             out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
         wd.cancel()
+        disarm()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -461,3 +461,24 @@ def test_conditioner_runs_each_embedder_once_for_c_and_uc():
     c3, uc3 = cond.get_unconditional_conditioning(batch, other, force)
     assert [s_.calls for s_ in stubs] == [b + 2 for b in before]
     assert torch.equal(c3["vector"], c["vector"]) and not torch.equal(uc3["vector"], c["vector"])
+
+
+def test_bench_line_guardian_prints_once_whatever_happens_to_the_process():
+    """bench.py's insurance around the optional RCCL leg: if the process aborts inside it, a detached helper prints the
+    headline line; if the leg returns, the process prints the complete line itself and the helper stays silent."""
+    import json
+    import subprocess
+    import sys
+    import time
+    prog = ("import os, sys, time\nsys.path.insert(0, %r)\nimport bench\n"
+            "disarm = bench.guard_line('{\"metric\": \"m\", \"value\": 1}')\n"
+            "mode = sys.argv[1]\n"
+            "if mode == 'abort':\n    os.abort()\n"
+            "disarm()\nprint('{\"metric\": \"m\", \"value\": 1, \"clip_parallel\": {}}', flush=True)\n") % ROOT
+    for mode, want in (("abort", {"metric": "m", "value": 1}), ("ok", {"metric": "m", "value": 1, "clip_parallel": {}})):
+        p = subprocess.Popen([sys.executable, "-c", prog, mode], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        out = p.stdout.read().decode()                 # (reads until the helper, which holds the pipe, has gone too)
+        p.wait()
+        lines = [l for l in out.splitlines() if l.strip()]
+        assert len(lines) == 1 and json.loads(lines[0]) == want, (mode, out)
+        assert (p.returncode != 0) == (mode == "abort")
