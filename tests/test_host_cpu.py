@@ -482,3 +482,81 @@ def test_bench_line_guardian_prints_once_whatever_happens_to_the_process():
         lines = [l for l in out.splitlines() if l.strip()]
         assert len(lines) == 1 and json.loads(lines[0]) == want, (mode, out)
         assert (p.returncode != 0) == (mode == "abort")
+
+
+def _header_prototypes():
+    """[(return type, name, [parameter C types])] of every function include/hi3d_hip.h declares"""
+    import re
+    src = open(os.path.join(ROOT, "include", "hi3d_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = []
+    for ret, name, args in re.findall(r"\n\s*((?:const\s+)?[A-Za-z_0-9]+\s*\*?)\s*(hi3d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src):
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [" ".join(a.split()).rsplit(" ", 1)[0].replace(" *", "*") for a in args.split(",")]
+        out.append((" ".join(ret.split()).replace(" *", "*"), name, params))
+    return out
+
+
+def test_ctypes_signatures_match_the_header():
+    """ABI drift check without a GPU: for every prototype of include/hi3d_hip.h the ctypes binding (hi3d_hip/lib.py) has
+    the same number of parameters, each of the same class (pointer / int32 / int64 / float), and the same return class."""
+    import ctypes as C
+    from hi3d_hip import lib as L
+    lib = L.load()
+
+    def c_class(t):
+        if t.endswith("*"):
+            return "ptr"
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "float": "f32"}[t]
+
+    def ct_class(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int32: "i32", C.c_int64: "i64", C.c_float: "f32"}[t]
+
+    protos = _header_prototypes()
+    assert len(protos) == len(L.EXPORTS) and {n for _, n, _ in protos} == set(L.EXPORTS)
+    for ret, name, params in protos:
+        fn = getattr(lib, name)
+        assert [c_class(p) for p in params] == [ct_class(a) for a in fn.argtypes], f"{name}: {params} vs {fn.argtypes}"
+        assert c_class(ret) == ct_class(fn.restype), f"{name}: return {ret} vs {fn.restype}"
+
+
+def test_abi_argument_validation_needs_no_gpu():
+    """Every entry point checks its arguments BEFORE touching the device: null pointers, non-positive sizes, shapes the kernels do
+    not have and misaligned pointers come back as HI3D_EINVAL / ESHAPE / EALIGN with a message naming the operation -- here on a
+    box without a GPU, so nothing can have been launched."""
+    import ctypes as C
+    from hi3d_hip import lib as L
+    lib = L.load()
+    EINVAL, ESHAPE, EALIGN = -1, -2, -3
+    p = C.c_void_p(4096)                      # a non-null, 16-byte aligned fake address: never dereferenced on these paths
+    odd = C.c_void_p(4097)
+    cases = [
+        ("hi3d_attn_d64", (None, p, p, p, 1, 1, 64, 64, 64, 64, 64, 64, 0.125, None), EINVAL, "attn_d64"),
+        ("hi3d_attn_d64", (p, p, p, p, 1, 1, 0, 64, 64, 64, 64, 64, 0.125, None), EINVAL, "attn_d64"),
+        ("hi3d_attn_d64", (p, p, p, p, 1, 1, 64, 64, 64, 64, 100, 64, 0.125, None), ESHAPE, "ld_vt"),
+        ("hi3d_attn_d64", (odd, p, p, p, 1, 1, 64, 64, 64, 64, 64, 64, 0.125, None), EALIGN, "misaligned"),
+        ("hi3d_attn_d64", (p, p, p, p, 1, 1, 64, 64, 64, 64, 64, 64, -1.0, None), EINVAL, "scale"),
+        ("hi3d_attn_temporal_d64", (p, p, p, p, 1, 33, 16, 1, 192, 64, 0.125, None), ESHAPE, "T > 32"),
+        ("hi3d_groupnorm_silu", (p, p, p, p, p, 1, 16, 48, 1e-5, 1, None), ESHAPE, "multiple of 32"),
+        ("hi3d_groupnorm_silu", (p, None, p, p, p, 1, 16, 64, 1e-5, 1, None), EINVAL, "groupnorm"),
+        ("hi3d_layernorm", (p, p, None, p, p, None, 1, 4, 4096, 1e-5, None), ESHAPE, "layernorm"),
+        ("hi3d_concat_channels", (p, p, p, 4, 12, 8, None), ESHAPE, "multiples of 8"),
+        ("hi3d_transpose_v", (p, p, 1, 1, 100, 100, 64, None), ESHAPE, "S_pad"),
+        ("hi3d_permute_rows", (p, p, (C.c_int32 * 4)(2, 2, 2, 2), (C.c_int32 * 4)(0, 0, 1, 2), 64, None), EINVAL, "not a permutation"),
+        ("hi3d_permute_rows", (p, p, (C.c_int32 * 4)(2, 2, 2, 2), (C.c_int32 * 4)(0, 1, 2, 3), 24, None), EALIGN, "16 bytes"),
+        ("hi3d_gemm_set_workspace", (p, 0), EINVAL, "gemm_set_workspace"),
+    ]
+    for name, args, want, frag in cases:
+        rc = getattr(lib, name)(*args)
+        msg = lib.hi3d_last_error().decode()
+        assert rc == want and frag in msg, f"{name}{args}: rc {rc} (want {want}), message {msg!r}"
+    d = L.GemmDesc()
+    assert lib.hi3d_gemm_bf16(C.byref(d), None) == EINVAL and "gemm" in lib.hi3d_last_error().decode()
+    d.A = d.W = d.out = 4096
+    d.M, d.N, d.K, d.lda, d.ldo, d.rows_per_group = 128, 128, 100, 100, 128, 1
+    assert lib.hi3d_gemm_bf16(C.byref(d), None) == ESHAPE and "multiple of 64" in lib.hi3d_last_error().decode()
+    d.K, d.lda, d.amode, d.Cin = 576, 576, L.A_CONV3X3, 60
+    assert lib.hi3d_gemm_bf16(C.byref(d), None) == ESHAPE and "conv3x3" in lib.hi3d_last_error().decode()
