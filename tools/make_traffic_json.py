@@ -40,8 +40,10 @@ def main():
             "launches_profiled": n,
             "fetch_KB_x2_corrected": int(2.0 * sf),
             "write_KB": int(sw),
-            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 1 --warmup 1; "
-                      "FETCH_SIZE doubled (gfx950 half-count for 16 B/lane streams, calibrated on layernorm)",
+            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only) on bench.py --steps 1 --warmup 1 "
+                      "--no-cpu-baseline --no-profile --no-legs with HI3D_STEP_GRAPH=0: 4 eager sampler steps and nothing else, so "
+                      "every profiled launch belongs to a step; FETCH_SIZE doubled (gfx950 half-count for 16 B/lane streams, "
+                      "calibrated on layernorm)",
         }
     # calibration: the C = 320 LayerNorm reads 524288 x 320 bf16 = 327,680 KB per launch at the 128^2 level
     cal = [v for k, v in fetch.items() if k.startswith("layernorm_packed_kernel<8>") or k.startswith("layernorm_kernel<1>")]
