@@ -315,6 +315,8 @@ def main():
         # BASELINE config 4's frame count through the full-width stage-2 UNet: temporal attention / Conv3d / 3-D GroupNorm over
         # 32 frames at every width (latent 16 x 16 so the reference finishes in about a minute)
         jobs["unet_s2_lat16_t32"] = lambda: gen_unet("unet_s2_lat16_t32", unet_cfg(2), T=32, hw=16, iseed=77, compact=True)
+        # ... and the same 32 views at latent 64 x 64 (4096-token spatial attention, 262144-row GEMMs; ~6 min, ~25 GB)
+        jobs["unet_s2_lat64_t32"] = lambda: gen_unet("unet_s2_lat64_t32", unet_cfg(2), T=32, hw=64, iseed=78, compact=True)
         # the temporal VideoDecoder (time_mode conv-only) at full width on a 4-frame clip of 256 x 256
         jobs["videodec_full_lat32"] = lambda: gen_video_decode("videodec_full_lat32", 128, 1, 4, 32, iseed=13)
         # encode_first_stage of one frame at the stage-2 resolution, full-width encoder (16384-token mid-block attention)

@@ -216,12 +216,17 @@ def test_unet_full_size_stage2_matches_reference_golden(dev, attn, monkeypatch):
     assert rel < tol and c > cmin
 
 
-def test_unet_full_width_32_views_matches_reference_golden(dev):
+@pytest.mark.parametrize("name", ["unet_s2_lat16_t32", "unet_s2_lat64_t32"])
+def test_unet_full_width_32_views_matches_reference_golden(dev, name):
     """BASELINE config 4 (32 views): the full-width stage-2 UNet (320 .. 1280 channels) at T = 32 -- CFG batch 64 -- on
-    latent 16 x 16 against one forward of the REFERENCE VideoUNet at T = 32 (round 2 compared with the oracle, itself pinned
-    at T = 4 .. 16 only): temporal attention over 32 frames, Conv3d and 3-D GroupNorm over 32 frames at every width."""
+    latent 16 x 16 and 64 x 64 (4096-token spatial attention, 262144-row GEMMs) against one forward of the REFERENCE
+    VideoUNet at T = 32 (round 2 compared with the oracle, itself pinned at T = 4 .. 16 only): temporal attention over 32
+    frames, Conv3d and 3-D GroupNorm over 32 frames at every width.  (The 128 x 128 latent of config 4 needs ~90 GB for the
+    reference on the CPU: not generated.)"""
     from hi3d_hip import synth
-    fx = load("unet_s2_lat16_t32")
+    if not os.path.exists(os.path.join(GOLD, name + ".pt")):
+        pytest.skip(f"{name}.pt not generated")
+    fx = load(name)
     T, hw, cfg = fx["T"], fx["hw"], fx["cfg"]
     inp = synth.synth_unet_inputs(cfg, T, hw, fx["input_seed"])
     pr = fx["input_probe"]
@@ -231,7 +236,7 @@ def test_unet_full_width_32_views_matches_reference_golden(dev):
             num_video_frames=T, image_only_indicator=inp["image_only_indicator"].to(dev))
     ref = fx["output"].float()
     rel, c = relerr(out, ref), cos(out, ref)
-    print(f"unet full width, 32 views, latent 16 vs reference: rel {rel:.4f} cos {c:.6f}")
+    print(f"unet full width, 32 views, latent {hw} vs reference: rel {rel:.4f} cos {c:.6f}")
     assert T == 32 and tuple(out.shape) == (2 * T, 4, hw, hw) == tuple(ref.shape) and rel < 4e-2 and c > 0.9995
 
 
