@@ -45,7 +45,14 @@ constexpr int Q_TILE = 4 * QB * 32;    // query rows per block
 
 // PRE: q arrives pre-multiplied by scale*log2(e) (the UNet runtime folds it into the to_q weights, one
 // rounding); otherwise the scale is applied to the fp32 score differences (one packed multiply per two scores).
-template <bool PRE>
+// VROW: V arrives ROW-major ([b][s][ldv] with this head's 64 channels at column h*64, e.g. the v block of a fused qkv
+// buffer; AttnParams.vt / ldvt then hold that pointer / row pitch) instead of as the pre-transposed V^T of
+// hi3d_transpose_v.  The 64-key tile is LDS-DMA'd as two [64 keys][32 d] images with 64-byte rows and the V^T fragments
+// of the second product are formed by ds_read_b64_tr_b16 (gfx950's transposing LDS read): a 16-lane group reads a
+// [4 keys][16 d] block and each lane receives 4 consecutive keys of ONE d column, so two reads give the 8-key A fragment
+// that the pre-transposed layout delivered with one ds_read_b128.  A 32-lane half touches 4 rows x 64 B = 256 contiguous
+// bytes per read (all 64 banks once).  Removes the transpose pass (1.2 ms per stage-2 step) and its 2 x V bytes.
+template <bool PRE, bool VROW>
 __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -82,14 +89,16 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   // 8 pieces of 1 KiB; wave w moves pieces 2w, 2w+1 of both.
   const int lrow = lane >> 3, lslot = lane & 7;
   const char* kbase = p.k + ((long)b * p.Skv * p.ldk + h * 64) * 2;
-  const char* vbase = p.vt + ((long)(b * p.H + h) * 64) * (long)p.ldvt * 2;
+  const char* vbase = VROW ? p.vt + ((long)b * p.Skv * p.ldvt + h * 64) * 2
+                           : p.vt + ((long)(b * p.H + h) * 64) * (long)p.ldvt * 2;
   // buffer-addressed LDS-DMA (as in gemm.hip): one descriptor per operand based at this (b, h), a 32-bit
   // per-lane byte offset fixed for the whole loop, a scalar offset walking the key tiles.  Key rows >= Skv lie
   // beyond num_records and read as zeros (no per-lane select, no 64-bit per-lane pointers).
 #if __HIP_DEVICE_COMPILE__
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
       (void*)kbase, 0, (int)min((long)0x7fffffff, ((long)p.Skv - 1) * p.ldk * 2 + 128), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(   // (VROW: rows >= Skv read as zeros, like K)
+      (void*)vbase, 0, VROW ? (int)min((long)0x7fffffff, ((long)p.Skv - 1) * p.ldvt * 2 + 128) : 0x7fffffff, 0x00020000);
   int k_vo[2], v_vo[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -97,7 +106,14 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     const int kc = lslot ^ ((swap_bits23(r & 31) >> 1) & 7);   // read by MFMA row swap(r)
     const int vc = lslot ^ ((r >> 1) & 7);
     k_vo[i] = r * p.ldk * 2 + kc * 16;
-    v_vo[i] = r * p.ldvt * 2 + vc * 16;
+    if (VROW) {
+      // piece q = 2w + i of the V tile: image db = q >> 2 ([64 keys][32 d], 64-byte rows), key rows (q & 3) * 16 .. + 15;
+      // lane -> key row lane >> 2, 16-byte chunk lane & 3 (the LDS image is lane-linear: row pitch 4 lanes x 16 B)
+      const int q = w * 2 + i;
+      v_vo[i] = ((q & 3) * 16 + (lane >> 2)) * p.ldvt * 2 + ((q >> 2) * 32 + (lane & 3) * 8) * 2;
+    } else {
+      v_vo[i] = r * p.ldvt * 2 + vc * 16;
+    }
   }
   auto issue = [&](int j, int st) {
     char* sK = smem + st * ATT_STAGE;
@@ -108,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (LDS_AS void*)(sK + (w * 2 + i) * 1024), 16, k_vo[i], kv0 * p.ldk * 2, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(sV + (w * 2 + i) * 1024), 16, v_vo[i], kv0 * 2, 0, 0);   // padded to 64: in range
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (LDS_AS void*)(sV + (w * 2 + i) * 1024), 16, v_vo[i],
+                                               VROW ? kv0 * p.ldvt * 2 : kv0 * 2, 0, 0);   // (V^T: padded to 64, in range)
   };
 #else
   auto issue = [&](int, int) {};
@@ -123,6 +140,9 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     k_ptr[ks] = smem + swap_bits23(li) * 128 + (((ks * 2 + hi) ^ f_sw) << 4);
     v_ptr[ks] = smem + KV_TILE * 128 + li * 128 + (((ks * 2 + hi) ^ f_sw) << 4);
   }
+  // VROW: one base for all 16 transposing reads of a tile (image db: + db * 4096, k-step: + ks * 1024, second 4 keys: + 256):
+  // lane (g = lane >> 4, i = lane & 15) addresses key row hi * 8 + (i >> 2), columns (g & 1) * 16 + (i & 3) * 4 .. + 3
+  const char* v_tr = smem + KV_TILE * 128 + (hi * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
   int stage_step = ATT_STAGE;
 
   f32x16 o[QB][2];
@@ -268,7 +288,16 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 vf = *(const bf16x8*)(v_ptr[ks] + db * 32 * 128);
+        bf16x8 vf;
+        if (VROW) {
+#if __HIP_DEVICE_COMPILE__
+          const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(v_tr + db * 4096 + ks * 1024));
+          const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(v_tr + db * 4096 + ks * 1024 + 256));
+          vf = bf16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#endif
+        } else {
+          vf = *(const bf16x8*)(v_ptr[ks] + db * 32 * 128);
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], o[qb][db], 0, 0, 0);
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
     // flip the fragment pointers to the other ring stage
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { k_ptr[ks] += stage_step; v_ptr[ks] += stage_step; }
+    v_tr += stage_step;
     stage_step = -stage_step;
   }
 
@@ -449,35 +479,62 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
 
 }  // namespace
 
-extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
-                             int32_t B, int32_t H, int32_t S_q, int32_t S_kv, int32_t ldq,
-                             int32_t ldk, int32_t ld_vt, int32_t ldo, float scale, void* stream) {
-  if (!q || !k || !vt || !out) HI3D_FAIL(HI3D_EINVAL, "attn_d64: null pointer");
+namespace {
+// shared launcher: vrow = 0 -> `v` is the pre-transposed V^T [B][H][64][ld_v] (hi3d_transpose_v), 1 -> row-major V, pitch ld_v
+int attn_d64_launch(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t S_q, int32_t S_kv,
+                    int32_t ldq, int32_t ldk, int32_t ld_v, int32_t ldo, float scale, int vrow, void* stream) {
+  if (!q || !k || !v || !out) HI3D_FAIL(HI3D_EINVAL, "attn_d64: null pointer");
   if (B <= 0 || H <= 0 || S_q <= 0 || S_kv <= 0) HI3D_FAIL(HI3D_EINVAL, "attn_d64: non-positive size");
   if (ldq < H * 64 || ldk < H * 64 || ldo < H * 64) HI3D_FAIL(HI3D_EINVAL, "attn_d64: leading dim < H*64");
   if ((ldq % 8) || (ldk % 8) || (ldo % 4)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: leading dims must keep 16-byte rows");
-  if (ld_vt % 64 || ld_vt < S_kv) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: ld_vt must be S_kv rounded up to 64");
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: misaligned pointer");
+  if (vrow) {
+    if (ld_v % 8 || ld_v < H * 64) HI3D_FAIL(HI3D_EALIGN, "attn_d64_v: ldv must be a multiple of 8 and >= H*64");
+  } else {
+    if (ld_v % 64 || ld_v < S_kv) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: ld_vt must be S_kv rounded up to 64");
+  }
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)out & 7)) HI3D_FAIL(HI3D_EALIGN, "attn_d64: misaligned pointer");
   if (!(scale >= 0.0f)) HI3D_FAIL(HI3D_EINVAL, "attn_d64: scale must be > 0 (or 0: q already carries scale*log2(e))");
   AttnParams p;
-  p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)vt; p.out = (unsigned short*)out;
-  p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_vt; p.ldo = ldo;
+  p.q = (const char*)q; p.k = (const char*)k; p.vt = (const char*)v; p.out = (unsigned short*)out;
+  p.B = B; p.H = H; p.Sq = S_q; p.Skv = S_kv; p.ldq = ldq; p.ldk = ldk; p.ldvt = ld_v; p.ldo = ldo;
   p.nqt = (S_q + Q_TILE - 1) / Q_TILE;
   { const char* e = getenv("HI3D_ATTN_FORCE_EXACT"); p.force_exact = (e && atoi(e)) ? 1 : 0; }
   p.scale_log2 = scale * 1.4426950408889634f;
   const long nblk = (long)p.nqt * H * B;
   if (nblk > 0x7fffffffL) HI3D_FAIL(HI3D_ESHAPE, "attn_d64: grid too large");
-  if (scale == 0.0f) hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_d64_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 g((unsigned)nblk), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (vrow) {
+    if (scale == 0.0f) hipLaunchKernelGGL((attn_d64_kernel<true, true>), g, blk, 0, s, p);
+    else hipLaunchKernelGGL((attn_d64_kernel<false, true>), g, blk, 0, s, p);
+  } else {
+    if (scale == 0.0f) hipLaunchKernelGGL((attn_d64_kernel<true, false>), g, blk, 0, s, p);
+    else hipLaunchKernelGGL((attn_d64_kernel<false, false>), g, blk, 0, s, p);
+  }
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
+}
+}  // namespace
+
+extern "C" int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
+                             int32_t B, int32_t H, int32_t S_q, int32_t S_kv, int32_t ldq,
+                             int32_t ldk, int32_t ld_vt, int32_t ldo, float scale, void* stream) {
+  return attn_d64_launch(q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, scale, 0, stream);
+}
+
+extern "C" int hi3d_attn_d64_v(const void* q, const void* k, const void* v, void* out,
+                               int32_t B, int32_t H, int32_t S_q, int32_t S_kv, int32_t ldq,
+                               int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+  return attn_d64_launch(q, k, v, out, B, H, S_q, S_kv, ldq, ldk, ldv, ldo, scale, 1, stream);
 }
 
 // debug aid: resident blocks per CU the runtime predicts for the spatial attention kernels (0: pre-scaled q, 1: scaled)
 extern "C" int hi3d_debug_attn_occupancy(int which) {
   int n = -1;
-  if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<true>, 256, 0);
-  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<false>, 256, 0);
+  if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<true, false>, 256, 0);
+  else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<false, false>, 256, 0);
+  else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<true, true>, 256, 0);
+  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_d64_kernel<false, true>, 256, 0);
   return n;
 }
 

@@ -36,10 +36,15 @@ struct GemmParams {
   // channel slabs for the conv gathers, whose K walks the taps innermost -- into the fp32 partial tile ks of `out`
   // ([ksplit][M][ldo], no bias / residual); splitk_combine_kernel sums the partials in a fixed order and applies the epilogue.
   int ksplit, nk_split;
+  // two-source dense A (internal amode A_DENSE2): columns [0, K1) of the logical A come from A (pitch lda), columns [K1, K) from
+  // A2 (pitch lda2) -- the decoder's skip concat `th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) as two K segments
+  // of the 1x1 skip_connection GEMM instead of a materialised [M, C1 + C2] tensor
+  const char* A2; int lda2, K1;
 };
 
 constexpr int BK = 64;
 constexpr int A_CONV3X3_UP2X = 3;   // internal: HI3D_A_CONV3X3 with up2x (own instantiation: the plain gather stays lean)
+constexpr int A_DENSE2 = 4;         // internal: HI3D_A_DENSE with two K segments from two tensors (GemmParams.A2)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
   constexpr bool UP2X = AMODE_ == A_CONV3X3_UP2X;
-  constexpr int AMODE = UP2X ? HI3D_A_CONV3X3 : AMODE_;
+  constexpr bool DENSE2 = AMODE_ == A_DENSE2;
+  constexpr int AMODE = UP2X ? HI3D_A_CONV3X3 : DENSE2 ? HI3D_A_DENSE : AMODE_;
   constexpr int BM = WM * 64, BN = 32 * NT;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
@@ -109,7 +115,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   int a_mask[4];                // conv: bit `tap` set when the tap is inside the image / clip
   int a_p0[4], a_p1[4];         // up2x only: output pixel coordinates
   const char* a_origin;
-  if (AMODE == HI3D_A_DENSE) {
+  unsigned a_voff2[DENSE2 ? 4 : 1];      // DENSE2: the same rows in the second source (its own pitch)
+  const int kt0 = DENSE2 ? ks * nk : 0;  // DENSE2 walks GLOBAL K chunks (the source switches at K1); plain dense folds ks into the bases
+  if (DENSE2) {
+    a_origin = p.A + (long)m0 * p.lda * 2;
+  } else if (AMODE == HI3D_A_DENSE) {
     a_origin = p.A + (long)m0 * p.lda * 2 + (long)ks * nk * (BK * 2);     // (split-K: this block's first K chunk)
   } else if (AMODE == HI3D_A_CONV3X3) {
     const int f0 = m0 / (p.Hout * p.Wout);
@@ -127,6 +137,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     a_mask[i] = 0; a_p0[i] = a_p1[i] = 0;
     if (AMODE == HI3D_A_DENSE) {
       a_voff[i] = ok ? (unsigned)(r * p.lda * 2 + chunk * 16) : INV;
+      if (DENSE2) a_voff2[i] = ok ? (unsigned)(r * p.lda2 * 2 + chunk * 16) : INV;
     } else if (AMODE == HI3D_A_CONV3X3) {
       const int hw = p.Hout * p.Wout;
       const int mm = ok ? m : m0;
@@ -167,6 +178,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     b_voff[i] = (n0 + j < p.N) ? (unsigned)(j * p.ldw * 2 + chunk * 16) : INV;
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_origin, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(DENSE2 ? p.A2 + (long)m0 * p.lda2 * 2 : a_origin), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.W + (long)n0 * p.ldw * 2 + (AMODE == HI3D_A_DENSE ? (long)ks * nk * (BK * 2) : 0L)), 0, 0x7fffffff, 0x00020000);
 
@@ -180,7 +193,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
     unsigned soff;                                 // scalar byte offset of this K chunk
-    if (AMODE == HI3D_A_DENSE) soff = kt * (BK * 2);
+    bool second = false;                           // DENSE2: this chunk lies in the second source (block-uniform)
+    if (DENSE2) { const int kc = (kt0 + kt) * BK; second = kc >= p.K1; soff = (second ? kc - p.K1 : kc) * 2; }
+    else if (AMODE == HI3D_A_DENSE) soff = kt * (BK * 2);
     else if (AMODE == HI3D_A_CONV3X3) soff = UP2X ? c0 * 2 : (((tap / 3) * p.Win + (tap % 3)) * p.Cin + c0) * 2;
     else soff = (tap * p.HW * p.Cin + c0) * 2;
 #pragma unroll
@@ -194,7 +209,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       } else if (AMODE != HI3D_A_DENSE) {
         vo = ((a_mask[i] >> tap) & 1) ? vo : INV;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(sA + (w * 4 + i) * 1024), 16, vo, soff, 0, 0);
+      if (DENSE2 && second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (LDS_AS void*)(sA + (w * 4 + i) * 1024), 16, a_voff2[i], soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(sA + (w * 4 + i) * 1024), 16, vo, soff, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
@@ -812,6 +830,12 @@ int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
   }
   switch (amode) {
     case HI3D_A_DENSE: return launch<WM, NT, NS, HI3D_A_DENSE, HI3D_EPI_AFFINE, PP>(p, s);
+    case A_DENSE2:
+      // (instantiated for the three tiles hi3d_gemm_bf16 restricts a two-source launch to)
+      if constexpr ((WM == 2 && NS == 2 && !PP) || (WM == 4 && NT == 10 && NS == 2 && PP))
+        return launch<WM, NT, NS, A_DENSE2, HI3D_EPI_AFFINE, PP>(p, s);
+      else
+        HI3D_FAIL(HI3D_EINVAL, "gemm: two-source A has no instantiation for this tile");
     case HI3D_A_CONV3X3: return p.up2x ? launch<WM, NT, NS, A_CONV3X3_UP2X, HI3D_EPI_AFFINE, PP>(p, s)
                                         : launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE, PP>(p, s);
     case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE, PP>(p, s);
@@ -891,7 +915,14 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.ldr1 = d->ldr1; p.ldr2 = d->ldr2; p.ldrv = d->ldrv > 0 ? d->ldrv : d->N; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.rpg = d->rows_per_group; p.out_fp32 = d->out_fp32;
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW; p.pad = d->pad_br_only ? 0 : 1;
-  if (d->amode == HI3D_A_DENSE) {
+  p.A2 = (const char*)d->A2; p.lda2 = d->lda2; p.K1 = d->K1;
+  const bool two = d->A2 != nullptr;
+  if (two) {
+    if (d->amode != HI3D_A_DENSE || d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: A2 (two-source A) needs dense A and the affine epilogue");
+    if (d->K1 <= 0 || d->K1 >= d->K || d->K1 % 64) HI3D_FAIL(HI3D_ESHAPE, "gemm: K1 must be a multiple of 64 inside (0, K)");
+    if (d->lda < d->K1 || d->lda % 8 || d->lda2 < d->K - d->K1 || d->lda2 % 8) HI3D_FAIL(HI3D_EALIGN, "gemm: lda < K1, lda2 < K - K1 or a pitch % 8 != 0");
+    if ((uintptr_t)d->A2 & 15) HI3D_FAIL(HI3D_EALIGN, "gemm: A2 not 16-byte aligned");
+  } else if (d->amode == HI3D_A_DENSE) {
     if (d->lda < d->K || (d->lda % 8)) HI3D_FAIL(HI3D_EALIGN, "gemm: lda < K or lda % 8 != 0");
   } else if (d->amode == HI3D_A_CONV3X3) {
     if (d->Cin <= 0 || d->Cin % 64 || d->K != 9 * d->Cin) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: need Cin % 64 == 0 and K == 9*Cin");
@@ -959,6 +990,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     variant = 8;
   }
   if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
+  if (two && variant != 7) variant = 0;           // two-source A: built for the 128-row 2-stage tile and the 256 x 320 ping-pong tile
   // split-K: a long-K launch that leaves most of the chip's 512 block slots (256 CUs x 2 blocks of the 128-row tile) empty
   // -- M = 1-4 K rows: the 8x8 level of stage 1 ran at 370 TFLOP/s, every level does on the ranks of a clip-parallel job --
   // is cut along K into `ksplit` blocks per tile in ONE grid; fp32 partial tiles go to the caller's workspace
@@ -996,6 +1028,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (const char* e = getenv("HI3D_GEMM_GN")) p.gn = atoi(e);
   }
   hipStream_t s = (hipStream_t)stream;
+  const int amode = two ? A_DENSE2 : d->amode;
   p.ksplit = 1; p.nk_split = d->K / BK;
   if (ksplit > 1) {
     int dev = -1;
@@ -1004,7 +1037,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     q.ksplit = ksplit; q.nk_split = d->K / BK / ksplit;
     q.out = g_ws[dev].ptr; q.out_fp32 = 1; q.ldo = d->N; q.vec8 = d->N % 8 == 0;
     q.bias = nullptr; q.rowvec = nullptr; q.R1 = nullptr; q.R2 = nullptr; q.a1 = nullptr; q.a2 = nullptr;
-    const int rc = tile == 160 ? dispatch<2, 5, 2>(q, d->amode, d->epi, s) : dispatch<2, 4, 2>(q, d->amode, d->epi, s);
+    const int rc = tile == 160 ? dispatch<2, 5, 2>(q, amode, d->epi, s) : dispatch<2, 4, 2>(q, amode, d->epi, s);
     if (rc || g_capture) return rc;
     CombineParams c{(const float*)g_ws[dev].ptr, d->bias, d->rowvec, (const unsigned short*)d->R1, (const unsigned short*)d->R2,
                     d->a1, d->a2, d->out, d->M, d->N, ksplit, d->ldo, d->ldr1, d->ldr2, p.ldrv, d->rows_per_group, d->out_fp32};
@@ -1013,10 +1046,11 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     HI3D_LAUNCH_CHECK();
     return HI3D_OK;
   }
-  if (tile == 256) return dispatch<4, 8, 2, true>(p, d->amode, d->epi, s);
-  if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, d->amode, d->epi, s) : dispatch<4, 10, 2>(p, d->amode, d->epi, s);
+  if (tile == 256) return dispatch<4, 8, 2, true>(p, amode, d->epi, s);
+  if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, amode, d->epi, s) : dispatch<4, 10, 2>(p, amode, d->epi, s);
   if (tile == 32) {
     if (d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: the 32-column tile has no GEGLU form");
+    if (two) HI3D_FAIL(HI3D_ESHAPE, "gemm: two-source A has no 32-column tile");
     p.nbm = (d->M + 127) / 128;
     switch (d->amode) {
       case HI3D_A_DENSE: return launch<2, 1, 2, HI3D_A_DENSE, HI3D_EPI_AFFINE>(p, s);
@@ -1026,17 +1060,17 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     }
   }
   if (tile == 160) {
-    if (variant == 6) return dispatch<4, 5, 3, true>(p, d->amode, d->epi, s);
-    if (variant == 2) return dispatch<4, 5, 3>(p, d->amode, d->epi, s);
-    if (variant == 1) return dispatch<2, 5, 3>(p, d->amode, d->epi, s);
-    if (variant == 3) return dispatch<2, 5, 1>(p, d->amode, d->epi, s);
-    return dispatch<2, 5, 2>(p, d->amode, d->epi, s);
+    if (variant == 6) return dispatch<4, 5, 3, true>(p, amode, d->epi, s);
+    if (variant == 2) return dispatch<4, 5, 3>(p, amode, d->epi, s);
+    if (variant == 1) return dispatch<2, 5, 3>(p, amode, d->epi, s);
+    if (variant == 3) return dispatch<2, 5, 1>(p, amode, d->epi, s);
+    return dispatch<2, 5, 2>(p, amode, d->epi, s);
   }
-  if (variant == 6) return dispatch<4, 4, 3, true>(p, d->amode, d->epi, s);
-  if (variant == 2) return dispatch<4, 4, 3>(p, d->amode, d->epi, s);
-  if (variant == 1) return dispatch<2, 4, 3>(p, d->amode, d->epi, s);
-  if (variant == 3) return dispatch<2, 4, 1>(p, d->amode, d->epi, s);
-  return dispatch<2, 4, 2>(p, d->amode, d->epi, s);
+  if (variant == 6) return dispatch<4, 4, 3, true>(p, amode, d->epi, s);
+  if (variant == 2) return dispatch<4, 4, 3>(p, amode, d->epi, s);
+  if (variant == 1) return dispatch<2, 4, 3>(p, amode, d->epi, s);
+  if (variant == 3) return dispatch<2, 4, 1>(p, amode, d->epi, s);
+  return dispatch<2, 4, 2>(p, amode, d->epi, s);
 }
 
 // debug aid: resident blocks per CU the runtime predicts for a kernel variant

@@ -31,15 +31,21 @@ __host__ __device__ inline int gn_threads(int C) {
   return vec * (256 / vec);                    // whole pixels per sweep, <= 256 threads
 }
 
-__global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial,
-                                int P, int C, int nblk, int ppb) {
+// Two-source form (x2 != nullptr): the normalised tensor is the channel concatenation [x | x2] -- C1 = 8 * vec1 channels from
+// x, the rest from x2 (the decoder's th.cat([h, hs.pop()], dim=1), video_model.py:490-499) -- read in place: a thread's
+// 16-byte channel chunk lies in exactly one source, so the only change is which base / pitch it walks.
+__global__ void gn_stats_kernel(const uint4* __restrict__ x, const uint4* __restrict__ x2, int vec1,
+                                float* __restrict__ partial, int P, int C, int nblk, int ppb) {
   __shared__ float gs[64];
   const int vec = C >> 3, cpg = C >> 5;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
+  const int chunk_all = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
   const int inst = blockIdx.y, blk = blockIdx.x;
   const int p_begin = blk * ppb, p_end = min(P, p_begin + ppb);
-  const uint4* base = x + (long)inst * P * vec;
+  const bool from2 = x2 != nullptr && chunk_all >= vec1;
+  const int pitch = x2 == nullptr ? vec : (from2 ? vec - vec1 : vec1);
+  const int chunk = from2 ? chunk_all - vec1 : chunk_all;
+  const uint4* base = (from2 ? x2 : x) + (long)inst * P * pitch;
   float s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
@@ -49,7 +55,7 @@ __global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__
   for (; p + (UNR - 1) * rows_per_sweep < p_end; p += UNR * rows_per_sweep) {
     uint4 v[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) v[u] = base[(long)(p + u * rows_per_sweep) * vec + chunk];
+    for (int u = 0; u < UNR; ++u) v[u] = base[(long)(p + u * rows_per_sweep) * pitch + chunk];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const unsigned int w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -62,7 +68,7 @@ __global__ void gn_stats_kernel(const uint4* __restrict__ x, float* __restrict__
     }
   }
   for (; p < p_end; p += rows_per_sweep) {
-    const uint4 v = base[(long)p * vec + chunk];
+    const uint4 v = base[(long)p * pitch + chunk];
     const unsigned int u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -152,13 +158,17 @@ __global__ void gn_from_sums_kernel(const double* __restrict__ sums, float* __re
 }
 
 template <bool SILU>
-__global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
+__global__ void gn_apply_kernel(const uint4* __restrict__ x, const uint4* __restrict__ x2, int vec1, uint4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ stats, int P, int C, int appb) {
   const int vec = C >> 3, cpg = C >> 5;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int chunk = tid % vec, rsub = tid / vec, rows_per_sweep = nthr / vec;
   const int inst = blockIdx.y;
+  // source of this thread's channel chunk (two-source form: see gn_stats_kernel); y is always the full-width tensor
+  const bool from2 = x2 != nullptr && chunk >= vec1;
+  const int xpitch = x2 == nullptr ? vec : (from2 ? vec - vec1 : vec1);
+  const uint4* xs = (from2 ? x2 + (chunk - vec1) : x + chunk) + (long)inst * P * xpitch;
   float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -185,13 +195,12 @@ __global__ void gn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
   for (; p + 3 * rows_per_sweep < p_end; p += 4 * rows_per_sweep) {
     uint4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = x[base + (long)(p + u * rows_per_sweep) * vec + chunk];
+    for (int u = 0; u < 4; ++u) v[u] = xs[(long)(p + u * rows_per_sweep) * xpitch];
 #pragma unroll
     for (int u = 0; u < 4; ++u) y[base + (long)(p + u * rows_per_sweep) * vec + chunk] = norm8(v[u]);
   }
   for (; p < p_end; p += rows_per_sweep) {
-    const long idx = base + (long)p * vec + chunk;
-    y[idx] = norm8(x[idx]);
+    y[base + (long)p * vec + chunk] = norm8(xs[(long)p * xpitch]);
   }
 }
 
@@ -343,9 +352,9 @@ extern "C" int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C) 
   return (int64_t)inst * hi3d_gn_partial_blocks(P, C) * 64 + (int64_t)inst * 64;
 }
 
-extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
-                                   float* ws, int32_t inst, int32_t P, int32_t C, float eps,
-                                   int32_t apply_silu, void* stream) {
+namespace {
+int groupnorm_launch(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta,
+                     float* ws, int32_t inst, int32_t P, int32_t C, float eps, int32_t apply_silu, void* stream) {
   if (!x || !y || !gamma || !beta || !ws) HI3D_FAIL(HI3D_EINVAL, "groupnorm: null pointer");
   if (inst <= 0 || P <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm: non-positive size");
   if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
@@ -356,7 +365,7 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   float* partial = ws;
   float* stats = ws + (long)inst * hi3d_gn_partial_blocks(P, C) * 64;
   const int nthr = gn_threads(C);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, partial, P, C, nblk, ppb);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, (const uint4*)x2, C1 / 8, partial, P, C, nblk, ppb);
   HI3D_LAUNCH_CHECK();
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, partial, stats, nblk, inv_count, eps);
@@ -364,11 +373,27 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
   const int ablk = (P + appb - 1) / appb;
   if (apply_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)x2, C1 / 8, (uint4*)y, gamma, beta, stats, P, C, appb);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)x2, C1 / 8, (uint4*)y, gamma, beta, stats, P, C, appb);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
+}
+}  // namespace
+
+extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
+                                   float* ws, int32_t inst, int32_t P, int32_t C, float eps,
+                                   int32_t apply_silu, void* stream) {
+  return groupnorm_launch(x, nullptr, C, y, gamma, beta, ws, inst, P, C, eps, apply_silu, stream);
+}
+
+extern "C" int hi3d_groupnorm_silu_cat2(const void* x1, const void* x2, void* y, const float* gamma, const float* beta,
+                                        float* ws, int32_t inst, int32_t P, int32_t C1, int32_t C2, float eps,
+                                        int32_t apply_silu, void* stream) {
+  if (!x2) HI3D_FAIL(HI3D_EINVAL, "groupnorm_cat2: null pointer");
+  if (C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8) HI3D_FAIL(HI3D_ESHAPE, "groupnorm_cat2: C1 and C2 must be positive multiples of 8");
+  if ((uintptr_t)x2 & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm_cat2: x2 not 16-byte aligned");
+  return groupnorm_launch(x1, x2, C1, y, gamma, beta, ws, inst, P, C1 + C2, eps, apply_silu, stream);
 }
 
 extern "C" int hi3d_groupnorm_partial_sums(const void* x, float* ws, double* sums, int32_t inst, int32_t P,
@@ -381,7 +406,7 @@ extern "C" int hi3d_groupnorm_partial_sums(const void* x, float* ws, double* sum
   const int ppb = gn_ppb(inst, P);
   const int nblk = (P + ppb - 1) / ppb;
   const int nthr = gn_threads(C);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, ws, P, C, nblk, ppb);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, (const uint4*)nullptr, 0, ws, P, C, nblk, ppb);
   HI3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_reduce_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, ws, sums, nblk);
   HI3D_LAUNCH_CHECK();
@@ -405,9 +430,9 @@ extern "C" int hi3d_groupnorm_apply_sums(const void* x, void* y, const float* ga
   const int ablk = (P + appb - 1) / appb;
   const int nthr = gn_threads(C);
   if (apply_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)nullptr, 0, (uint4*)y, gamma, beta, stats, P, C, appb);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (uint4*)y, gamma, beta, stats, P, C, appb);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)nullptr, 0, (uint4*)y, gamma, beta, stats, P, C, appb);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

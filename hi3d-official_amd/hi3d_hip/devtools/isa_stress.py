@@ -165,12 +165,17 @@ class Module:
 
 
 # ---- the attention kernel of csrc/attention.hip ---------------------------------------------------------------------
-ATTN_SYMBOL = {True: "_ZN12_GLOBAL__N_115attn_d64_kernelILb1EEEvNS_10AttnParamsE",      # q pre-scaled
-               False: "_ZN12_GLOBAL__N_115attn_d64_kernelILb0EEEvNS_10AttnParamsE"}
+def attn_symbol(pre, vrow):
+    """attn_d64_kernel<PRE, VROW>: q pre-scaled / V row-major (transposing LDS reads) instead of the pre-transposed V^T."""
+    return f"_ZN12_GLOBAL__N_115attn_d64_kernelILb{int(pre)}ELb{int(vrow)}EEEvNS_10AttnParamsE"
+
+
+ATTN_SYMBOL = {True: attn_symbol(True, False), False: attn_symbol(False, False)}      # (the V^T form, by `pre`)
 
 
 def attn_kernarg(q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, scale):
-    """struct AttnParams of csrc/attention.hip (4 pointers, 10 ints incl. force_exact = 0, scale * log2 e)."""
+    """struct AttnParams of csrc/attention.hip (4 pointers, 10 ints incl. force_exact = 0, scale * log2 e).
+    VROW instantiations: vt = the row-major V pointer, ld_vt = its row pitch."""
     nqt = (S_q + 255) // 256
     return struct.pack("<4Q10if", q, k, vt, out, B, H, S_q, S_kv, ldq, ldk, ld_vt, ldo, nqt, 0, scale * 1.4426950408889634), nqt * H * B
 

@@ -74,13 +74,13 @@ def _chk_dev(*ts):
 
 def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None):
     """(hi3d_gemm_desc, out) of gemm(...) with the same arguments -- built, not launched (gemm() launches it; the ISA stress
     tool hands it to hi3d_debug_gemm_launch_info).  out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
     """
-    _chk_dev(A, W, out, bias, rowvec, R1, R2, a1, a2)
+    _chk_dev(A, W, out, bias, rowvec, R1, R2, a1, a2, A2)
     n_out = N // 2 if geglu else N
     if out is None:
         out = torch.empty((M, n_out), device=A.device, dtype=torch.float32 if out_fp32 else torch.bfloat16)
@@ -88,7 +88,9 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
     d.A, d.W, d.bias, d.rowvec = _p(A), _p(W), _p(bias), _p(rowvec)
     d.R1, d.R2, d.a1, d.a2, d.out = _p(R1), _p(R2), _p(a1), _p(a2), _p(out)
     d.M, d.N, d.K = M, N, K
-    d.lda = K if lda is None else lda
+    d.lda = (K if A2 is None else K1) if lda is None else lda
+    if A2 is not None:                       # logical A = [A | A2]: columns [0, K1) from A, [K1, K) from A2
+        d.A2, d.K1, d.lda2 = _p(A2), K1, (K - K1 if lda2 is None else lda2)
     d.ldo = out.stride(0) if out.dim() == 2 else n_out
     d.ldr1 = R1.stride(-2) if R1 is not None else 0
     d.ldr2 = R2.stride(-2) if R2 is not None else 0
@@ -132,13 +134,15 @@ def _ensure_gemm_workspace(dev):
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None):
     """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
+    A2 / K1: two-source dense A -- logical A = [A[:, :K1] | A2[:, :K - K1]] (the decoder's skip concat, never materialised).
     """
     d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
-                       a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n)
+                       a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n,
+                       A2=A2, K1=K1, lda2=lda2)
     _ensure_gemm_workspace(A.device)
     n_out = N // 2 if geglu else N
     prof = PROFILER
@@ -189,7 +193,24 @@ def attention_d64(q, k, vt, B, H, S_q, S_kv, ldq, ldk, scale, out=None):
     return out
 
 
+def attention_d64_v(q, k, v, B, H, S_q, S_kv, ldq, ldk, ldv, scale, out=None):
+    """attention_d64 with V ROW-major (v: tensor whose data_ptr is V[b=0, s=0, h=0, d=0], row pitch ldv): the kernel forms the
+    V^T fragments with gfx950's transposing LDS read -- no transpose pass, no V^T buffer."""
+    _chk_dev(q, k, v, out)
+    if out is None:
+        out = torch.empty((B * S_q, H * 64), device=q.device, dtype=torch.bfloat16)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_attn_d64_v(_p(q), _p(k), _p(v), _p(out), B, H, S_q, S_kv, ldq, ldk, ldv, out.stride(0), float(scale), _stream()),
+             "hi3d_attn_d64_v")
+    if prof:
+        prof.end("attn_d64", 4.0 * B * H * S_q * S_kv * 64, 2.0 * B * H * 64 * (2 * S_q + 2 * S_kv), t0)
+    return out
+
+
 Q_PRESCALE = 64 ** -0.5 * 1.4426950408889634   # softmax scale * log2(e): folded into to_q by pack_qkv(..., q_scale=)
+# HI3D_ATTN_VROW=0: the round-1..3 form (transpose_v pass + pre-transposed V^T operand) -- A/B switch, both are HIP paths
+ATTN_VROW = os.environ.get("HI3D_ATTN_VROW", "1") != "0"
 
 
 def self_attention_fused_qkv(qkv, B, S, H, scale=None, q_prescaled=False):
@@ -198,6 +219,8 @@ def self_attention_fused_qkv(qkv, B, S, H, scale=None, q_prescaled=False):
     C = H * 64
     assert qkv.shape == (B * S, 3 * C) and qkv.is_contiguous()
     scale = 0.0 if q_prescaled else (64 ** -0.5 if scale is None else scale)
+    if ATTN_VROW:
+        return attention_d64_v(qkv, qkv[:, C:], qkv[:, 2 * C:], B, H, S, S, 3 * C, 3 * C, 3 * C, scale)
     vt = transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
     return attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
 
@@ -267,18 +290,26 @@ def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
 _gn_ws = {}
 
 
-def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None):
+def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None, x2=None):
     """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32).
+    x2: second source -- the normalised tensor is the channel concatenation [x | x2] (C = C1 + C2 total channels, x holds
+    C1 = x.shape[-1] of them), read in place; the result is the full-width [inst*P, C] tensor.
     (Tried, MI355X: processing runs of instances that fit the 256 MB Infinity Cache so that the second read of x
     hits it -- 0.204 -> 0.236-0.248 ms at [32 x 16384 x 320]: the smaller grids cost more than the re-read.)"""
-    _chk_dev(x, gamma, beta, out)
-    assert x.is_contiguous() and x.numel() == inst * P * C
-    if out is None:
-        out = torch.empty_like(x)
-    return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out)
+    _chk_dev(x, gamma, beta, out, x2)
+    if x2 is None:
+        assert x.is_contiguous() and x.numel() == inst * P * C
+        if out is None:
+            out = torch.empty_like(x)
+    else:
+        C1 = x.numel() // (inst * P)
+        assert x.is_contiguous() and x2.is_contiguous() and x.numel() == inst * P * C1 and x2.numel() == inst * P * (C - C1)
+        if out is None:
+            out = torch.empty((inst * P, C), device=x.device, dtype=torch.bfloat16)
+    return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2)
 
 
-def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out):
+def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2=None):
     n = _lib.hi3d_gn_workspace_floats(inst, P, C)
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)
@@ -287,8 +318,13 @@ def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out):
         _gn_ws[key] = ws
     prof = PROFILER
     t0 = prof.begin() if prof else None
-    _l.check(_lib.hi3d_groupnorm_silu(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
-                                      float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu")
+    if x2 is None:
+        _l.check(_lib.hi3d_groupnorm_silu(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
+                                          float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu")
+    else:
+        C1 = x.numel() // (inst * P)
+        _l.check(_lib.hi3d_groupnorm_silu_cat2(_p(x), _p(x2), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C1, C - C1,
+                                               float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu_cat2")
     if prof:   # algorithmic bytes: read x once + write y once; the kernel reads x twice
         prof.end("groupnorm_silu", 0.0, 2.0 * 2 * inst * P * C, t0)
     return out

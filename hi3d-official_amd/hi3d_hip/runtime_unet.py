@@ -80,6 +80,8 @@ class UNetRuntime:
         self.layout = unet_layout(cfg)
         # HI3D_FUSED_FFN=0 falls back to the two-GEMM feed-forward (A/B switch; both are HIP paths)
         self.fused_ffn = os.environ.get("HI3D_FUSED_FFN", "1") != "0"
+        # HI3D_CAT_FUSED=0: materialise the decoder's skip concat (hi3d_concat_channels) as rounds 1-3 did (A/B switch)
+        self.cat_fused = os.environ.get("HI3D_CAT_FUSED", "1") != "0"
         # HI3D_ATTN_FP8QK=1: spatial attention scores on the fp8 matrix path (BASELINE config 5; reduced precision,
         # own tolerance) instead of bf16
         self.attn_fp8qk = os.environ.get("HI3D_ATTN_FP8QK", "0") == "1"
@@ -266,20 +268,27 @@ class UNetRuntime:
         return self._pos_cache[key]
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all, sp=None, emb_full=None, B=None):
+    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all, sp=None, emb_full=None, B=None, x2=None):
         """VideoResBlock (video_model.py:62-81).  F_: frames held by this GPU.  With `sp` (a
         hi3d_hip.parallel.FrameSpaceGroup) the spatial ResBlock runs on this GPU's frames, the temporal one
-        on its pixels of ALL frames (all-to-all before and after, GroupNorm sums all-reduced)."""
+        on its pixels of ALL frames (all-to-all before and after, GroupNorm sums all-reduced).
+        x2: the block input is the channel concatenation [x | x2] (`th.cat([h, hs.pop()], dim=1)`, video_model.py:490-499;
+        Cin = both widths together), read in place by the two consumers -- the in_layers GroupNorm and the 1x1
+        skip_connection as two K segments -- instead of being materialised (round 4; HI3D_CAT_FUSED=0 restores the copy)."""
         W, HW = self.W, H * Wd
         B = F_ // T if B is None else B
         M = F_ * HW
         geo = dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0)
         eo, _ = self.emb_slices[p]
-        h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5)
+        h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5, x2=x2)
         h = ops.gemm(h, W[p + ".in_layers.2.w"], M=M, N=Cout, K=9 * Cin, bias=W[p + ".in_layers.2.b"],
                      rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, conv3x3=geo)
         h = ops.groupnorm_silu(h, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.b"], F_, HW, Cout, 1e-5)
-        skip = x if (p + ".skip.w") not in W else self._linear(x, p + ".skip", M)
+        if x2 is not None:     # (Cin = C1 + C2 != Cout: the reference builds a skip_connection conv for every decoder ResBlock)
+            C1 = x.numel() // M
+            skip = ops.gemm(x, W[p + ".skip.w"], M=M, N=Cout, K=Cin, bias=W[p + ".skip.b"], A2=x2, K1=C1)
+        else:
+            skip = x if (p + ".skip.w") not in W else self._linear(x, p + ".skip", M)
         geo2 = dict(geo, Cin=Cout)
         xs = ops.gemm(h, W[p + ".out_layers.3.w"], M=M, N=Cout, K=9 * Cout, bias=W[p + ".out_layers.3.b"],
                       R1=skip, conv3x3=geo2)
@@ -392,7 +401,7 @@ class UNetRuntime:
         h, hs = x_tok, []
         cur = {"H": H, "W": Wd, "C": CIN_PAD}
 
-        def run(h, layers, base):
+        def run(h, layers, base, h2=None):
             for j, L in enumerate(layers):
                 p = f"{base}.{j}"
                 Hc, Wc = cur["H"], cur["W"]
@@ -401,7 +410,8 @@ class UNetRuntime:
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
                     cur["C"] = mc
                 elif L[0] == "res":
-                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all, emb_full=emb_full, **kw)
+                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all, emb_full=emb_full, x2=h2, **kw)
+                    h2 = None
                     cur["C"] = L[2]
                 elif L[0] == "attn":
                     h = self._transformer(p, h, L[1], F_, Hc * Wc, T, cond, a1_all, a_all, **kw)
@@ -422,8 +432,13 @@ class UNetRuntime:
         h = run(h, middle, "middle_block")
         for i, layers in enumerate(blocks_out):
             s, sc = hs.pop()
-            h = ops.concat_channels(h, s, F_ * cur["H"] * cur["W"], cur["C"], sc)     # th.cat (video_model.py:491)
-            h = run(h, layers, f"output_blocks.{i}")
+            fuse = self.cat_fused and layers[0][0] == "res" and cur["C"] % 64 == 0 and sc % 8 == 0 and \
+                (f"output_blocks.{i}.0.skip.w") in W
+            if fuse:           # th.cat (video_model.py:491) as a second source of the ResBlock's two readers
+                h = run(h, layers, f"output_blocks.{i}", h2=s)
+            else:
+                h = ops.concat_channels(h, s, F_ * cur["H"] * cur["W"], cur["C"], sc)
+                h = run(h, layers, f"output_blocks.{i}")
         Hc, Wc = cur["H"], cur["W"]
         h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], F_, Hc * Wc, mc, 1e-5)
         oc = self.cfg["out_channels"]

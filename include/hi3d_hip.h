@@ -102,6 +102,12 @@ typedef struct hi3d_gemm_desc {
   int32_t pad_br_only;  /* conv3x3: 1 = zero padding only at bottom/right (taps
                            cover iy = oy*stride + 0..2): the VAE encoder's
                            Downsample, model.py:76-90; 0 = padding 1 all round */
+  /* Two-source dense A (round 4; all zero = off): logical A = [A | A2] -- columns [0, K1) from A (pitch lda >= K1), columns
+   * [K1, K) from A2 (pitch lda2 >= K - K1) -- so the decoder's `h = th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499)
+   * feeds the ResBlock's 1x1 skip_connection (openaimodel.py:314) as two K segments and the concatenated tensor is never
+   * written.  HI3D_A_DENSE + HI3D_EPI_AFFINE only; K1 % 64 == 0. */
+  const void* A2;
+  int32_t K1, lda2;
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
@@ -136,6 +142,14 @@ int hi3d_attn_d64(const void* q, const void* k, const void* vt, void* out,
                   int32_t B, int32_t H, int32_t S_q, int32_t S_kv,
                   int32_t ldq, int32_t ldk, int32_t ld_vt /* = S_pad */, int32_t ldo,
                   float scale, void* stream);
+/* The same attention with V ROW-major, as the fused QKV projection leaves it (attention.py:332-336: `v = self.to_v(context)`
+ * then "b n (h d) -> (b h) n d"): v rows of 64 contiguous bf16 at base + (b*S_kv + s)*ldv + h*64.  The kernel builds the V^T
+ * fragments of P V with gfx950's transposing LDS read, so hi3d_transpose_v and the V^T buffer disappear from the call site
+ * (round 4; the UNet / ViT runtimes call this form).  Same numerics as hi3d_attn_d64 (bit-identical products).      */
+int hi3d_attn_d64_v(const void* q, const void* k, const void* v, void* out,
+                    int32_t B, int32_t H, int32_t S_q, int32_t S_kv,
+                    int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                    float scale, void* stream);
 
 /* Spatial self-attention with the score product on the CDNA4 fp8 matrix path (BASELINE.json config 5,
  * "fp8 MFMA attention + bf16 conv"): same attention as hi3d_attn_d64 (attention.py:332-336 / 427-439) with
@@ -195,6 +209,13 @@ int64_t hi3d_gn_workspace_floats(int32_t inst, int32_t P, int32_t C);
 int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
                         float* ws, int32_t inst, int32_t P, int32_t C,
                         float eps, int32_t apply_silu, void* stream);
+/* The same on the channel concatenation [x1 | x2] read IN PLACE (x1[inst][P][C1], x2[inst][P][C2], y[inst][P][C1 + C2]): the
+ * decoder's `h = th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) followed by the ResBlock's in_layers GroupNorm
+ * (openaimodel.py:257-259) without the concatenated tensor ever being written (round 4).  C1, C2 multiples of 8,
+ * (C1 + C2) % 32 == 0; ws as hi3d_gn_workspace_floats(inst, P, C1 + C2).                                        */
+int hi3d_groupnorm_silu_cat2(const void* x1, const void* x2, void* y, const float* gamma, const float* beta,
+                             float* ws, int32_t inst, int32_t P, int32_t C1, int32_t C2,
+                             float eps, int32_t apply_silu, void* stream);
 
 /* GroupNorm(32)+SiLU whose instance is spread over several GPUs -- the 3-D time_stack norm
  * (statistics over t,h,w: util.py:274-276 applied to 'b c t h w', video_model.py:71-76) of a clip

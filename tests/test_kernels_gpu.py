@@ -72,6 +72,45 @@ def test_gemm_geglu(dev, M, Nh, K):
     assert relerr(out, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("M,N,K1,K2,variant", [(300, 320, 320, 320, None), (700, 640, 128, 64, None), (513, 128, 64, 192, None),
+                                               (700, 640, 640, 320, 7), (2048, 1280, 1280, 1280, None), (130, 320, 64, 64, 0)])
+def test_gemm_two_source_A(dev, M, N, K1, K2, variant, monkeypatch):
+    """Two-source dense A (hi3d_gemm_desc.A2 / K1: the decoder's skip concat as two K segments of the 1x1 skip_connection,
+    video_model.py:490-499 + openaimodel.py:314) against the same launch on the materialised concatenation: the K walk
+    visits the same chunks in the same order, so the results are bit-identical; and against the fp32 reference.  Covers the
+    128 / 160-column tiles, the 256 x 320 ping-pong tile, the split-K path (M = 2048, K = 2560) and M / N tails."""
+    from hi3d_hip import ops
+    if variant is not None:
+        monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
+    K = K1 + K2
+    A1, A2, W = bf(rnd((M, K1), 1)), bf(rnd((M, K2), 2)), bf(rnd((N, K), 3, K ** -0.5))
+    bias, R1 = rnd((N,), 4), bf(rnd((M, N), 5))
+    cat = torch.cat([A1, A2], 1).contiguous()
+    ref = cat.float() @ W.float().T + bias + R1.float()
+    kw = dict(M=M, N=N, K=K, bias=bias.to(dev), R1=R1.to(dev))
+    two = ops.gemm(A1.to(dev), W.to(dev), A2=A2.to(dev), K1=K1, **kw)
+    assert relerr(two, ref) < BF16_TOL
+    if variant is None:
+        monkeypatch.setenv("HI3D_GEMM_VARIANT", "0")     # the tile a two-source launch is restricted to (below the wide tile)
+    one = ops.gemm(cat.to(dev), W.to(dev), **kw)
+    assert torch.equal(one, two)
+    # sources that sit inside wider buffers (pitch > width)
+    P1, P2 = bf(rnd((M, K1 + 64), 6)), bf(rnd((M, K2 + 8), 7))
+    P1[:, :K1], P2[:, :K2] = A1, A2
+    pit = ops.gemm(P1.to(dev), W.to(dev), A2=P2.to(dev), K1=K1, lda=K1 + 64, lda2=K2 + 8, **kw)
+    assert torch.equal(pit, two)
+
+
+def test_gemm_two_source_A_rejects(dev):
+    from hi3d_hip import ops
+    from hi3d_hip.lib import Hi3dError
+    A1, A2, W = bf(rnd((64, 64), 1)).to(dev), bf(rnd((64, 64), 2)).to(dev), bf(rnd((128, 128), 3)).to(dev)
+    with pytest.raises(Hi3dError):
+        ops.gemm(A1, W, M=64, N=128, K=128, A2=A2, K1=32)            # K1 not a multiple of 64
+    with pytest.raises(Hi3dError):
+        ops.gemm(A1, W, M=64, N=128, K=128, A2=A2, K1=64, geglu=True)  # no GEGLU form
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7, 8])
 def test_gemm_tile_variants(dev, variant, monkeypatch):
     """The tile variants the host heuristic picks only for large shapes (256-row tiles, single-stage
@@ -319,6 +358,25 @@ def test_gemm_split_k(dev, kind):
     assert relerr(out, plain.float().cpu()) < 8e-3                      # same math, different fp32 summation order + one bf16 rounding
 
 
+@pytest.mark.parametrize("inst,P,C1,C2,silu", [(3, 100, 64, 64, True), (2, 777, 320, 640, True), (2, 64, 1280, 1280, False),
+                                                 (1, 4096, 640, 320, True), (4, 9, 8, 56, True)])
+def test_groupnorm_cat2(dev, inst, P, C1, C2, silu):
+    """hi3d_groupnorm_silu_cat2 (GroupNorm over the channel concatenation of two tensors read in place -- the decoder's
+    th.cat + in_layers GroupNorm, video_model.py:490-499 / openaimodel.py:257-259) against hi3d_groupnorm_silu on the
+    materialised concatenation (bit-identical: same per-thread sums, same reduction order) and against F.group_norm."""
+    from hi3d_hip import ops
+    C = C1 + C2
+    x1, x2 = bf(rnd((inst * P, C1), 1, 2.0) + 0.3), bf(rnd((inst * P, C2), 2, 0.7) - 0.2)
+    g, b = rnd((C,), 3).abs() + 0.5, rnd((C,), 4)
+    cat = torch.cat([x1, x2], 1).contiguous()
+    a = ops.groupnorm_silu(cat.to(dev), g.to(dev), b.to(dev), inst, P, C, 1e-5, silu=silu)
+    c = ops.groupnorm_silu(x1.to(dev), g.to(dev), b.to(dev), inst, P, C, 1e-5, silu=silu, x2=x2.to(dev))
+    assert c.shape == (inst * P, C) and torch.equal(a, c)
+    ref = F.group_norm(cat.float().reshape(inst, P, C).permute(0, 2, 1), 32, g, b, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(inst * P, C)
+    assert relerr(c, ref) < BF16_TOL
+
+
 @pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 2, 16), (1, 1, 4), (1, 3, 129)])
 def test_attention_d64(dev, B, H, S):
     from hi3d_hip import ops
@@ -348,11 +406,10 @@ def test_attention_d64_ragged_repeatable(dev, S, force_exact, monkeypatch):
     qkv = bf(rnd((B * S, 3 * C), 17 + S, 1.5)).to(dev)
     first = ops.self_attention_fused_qkv(qkv, B, S, H)
     ring = [torch.empty_like(first) for _ in range(25)]
-    vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
     bad = 0
-    for rnd_ in range(40):                                   # 40 x 25 = 1000 launches
+    for rnd_ in range(40):                                   # 40 x 25 = 1000 launches (the row-major-V form the runtimes call)
         for o in ring:
-            ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, 64 ** -0.5, out=o)
+            ops.attention_d64_v(qkv, qkv[:, C:], qkv[:, 2 * C:], B, H, S, S, 3 * C, 3 * C, 3 * C, 64 ** -0.5, out=o)
         bad += int(torch.stack([(o != first).any() for o in ring]).sum())
     assert bad == 0, f"{bad} of 1000 launches differ from the first"
     q, k, v = [t.float().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(C, dim=1)]
@@ -360,19 +417,21 @@ def test_attention_d64_ragged_repeatable(dev, S, force_exact, monkeypatch):
     assert relerr(first, ref) < 2e-2
 
 
+@pytest.mark.parametrize("vrow", [False, True])
 @pytest.mark.parametrize("pre", [False, True])
-def test_attention_isa_timing_stress(dev, pre, tmp_path):
+def test_attention_isa_timing_stress(dev, pre, vrow, tmp_path):
     """The shipped attention kernels with idle wait states / waits / VALU no-ops patched into their DEVICE ASSEMBLY
     (hi3d_hip.devtools.isa_stress: after every MFMA, before every MFMA, after every packed-fp32 / exp / VALU instruction,
     adjacent MFMAs split, the barrier delayed ...), two blocks per CU: bit-identical to the library's own launch, in every
     launch, at a full and at a ragged length.  Wait states cannot change what a correct program computes; the round-2 build
-    of this kernel failed EVERY launch under the first of these patches (gpurun_out -> profiles/r03a_asm_lab*.log)."""
+    of this kernel failed EVERY launch under the first of these patches (gpurun_out -> profiles/r03a_asm_lab*.log).
+    vrow: the round-4 form that reads V row-major through ds_read_b64_tr_b16 (the one the runtimes call)."""
     import os
     from hi3d_hip import ops
     from hi3d_hip.devtools import isa_stress as I
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = I.device_asm(os.path.join(root, "hi3d-official_amd", "csrc", "attention.hip"))
-    sym = I.ATTN_SYMBOL[pre]
+    sym = I.attn_symbol(pre, vrow)
     B, H = 16, 12
     C = H * 64
     st = torch.cuda.current_stream().cuda_stream
@@ -382,18 +441,45 @@ def test_attention_isa_timing_stress(dev, pre, tmp_path):
         mod = I.Module(I.assemble(pl, str(tmp_path / (name + ".hsaco"))))
         for S in (576, 577):
             qkv = bf(rnd((B * S, 3 * C), 23, 1.5)).to(dev)
-            vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
             scale = 0.0 if pre else 0.125
-            ref = ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
+            if vrow:
+                vop, ldv = qkv[:, 2 * C:], 3 * C
+                ref = ops.attention_d64_v(qkv, qkv[:, C:], vop, B, H, S, S, 3 * C, 3 * C, 3 * C, scale)
+            else:
+                vop = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+                ldv = vop.shape[-1]
+                ref = ops.attention_d64(qkv, qkv[:, C:], vop, B, H, S, S, 3 * C, 3 * C, scale)
             outs = [torch.empty_like(ref) for _ in range(20)]
             for o in outs:
-                arg, grid = I.attn_kernarg(qkv.data_ptr(), qkv[:, C:].data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, S, S, 3 * C, 3 * C,
-                                           vt.shape[-1], C, scale)
+                arg, grid = I.attn_kernarg(qkv.data_ptr(), qkv[:, C:].data_ptr(), vop.data_ptr(), o.data_ptr(), B, H, S, S, 3 * C, 3 * C,
+                                           ldv, C, scale)
                 mod.launch(sym, grid, 256, arg, st)
             torch.cuda.synchronize()
             nbad = sum(int(not torch.equal(o, ref)) for o in outs)
             assert nbad == 0, f"patch {name}, S={S}: {nbad} of 20 launches differ from the unpatched kernel"
         mod.close()
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 3, 129), (3, 4, 577), (1, 1, 4)])
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_d64_v_rowmajor_equals_transposed(dev, B, H, S, pre):
+    """hi3d_attn_d64_v (V row-major, V^T fragments by ds_read_b64_tr_b16) against hi3d_attn_d64 on hi3d_transpose_v's output:
+    the two feed the same bf16 values to the same MFMAs in the same order, so the outputs are BIT-identical -- including a V
+    operand that sits in a wider buffer with other data behind the last key row (the fused qkv layout: rows >= S_kv of the last
+    key tile must come back as zeros from the buffer bound, not as the next batch's rows)."""
+    from hi3d_hip import ops
+    C = H * 64
+    qkv = bf(rnd((B * S, 3 * C), 5 + S, 1.5)).to(dev)
+    scale = 0.0 if pre else 0.125
+    vt = ops.transpose_v(qkv[:, 2 * C:], B, H, S, 3 * C)
+    a = ops.attention_d64(qkv, qkv[:, C:], vt, B, H, S, S, 3 * C, 3 * C, scale)
+    b = ops.attention_d64_v(qkv, qkv[:, C:], qkv[:, 2 * C:], B, H, S, S, 3 * C, 3 * C, 3 * C, scale)
+    assert torch.equal(a, b)
+    # NaN behind the last row of the LAST batch must not leak in either (poisoned tail of a larger allocation)
+    big = torch.full((B * S + 64, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    big[:B * S] = qkv
+    c = ops.attention_d64_v(big, big[:, C:], big[:, 2 * C:], B, H, S, S, 3 * C, 3 * C, 3 * C, scale)
+    assert torch.equal(a, c)
 
 
 def test_attention_d64_online_softmax_rescale(dev):

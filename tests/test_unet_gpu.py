@@ -275,3 +275,24 @@ def test_unet_fp8_attention_paths(dev, monkeypatch, mode):
     assert d > 0
     tol, cmin = {"fp8qk": (8e-2, 0.998), "fp8": (1.2e-1, 0.995)}[mode]
     assert rel < tol and cos > cmin
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_s2_ioi", "unet_s1_lat16"])
+def test_unet_skip_concat_in_place_equals_materialised(dev, monkeypatch, name):
+    """Round 4: the decoder's `h = th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) is read in place by its two
+    consumers (two-source GroupNorm, two K segments of the 1x1 skip_connection) instead of being written.  Against the same
+    model with the copy (HI3D_CAT_FUSED=0): bit-identical, and the attention's row-major-V form against the transpose pass
+    (HI3D_ATTN_VROW=0) likewise -- neither change touches a single arithmetic operation."""
+    import importlib
+    from hi3d_hip import ops
+    fx = load(name)
+    i = {k: v.to(dev) for k, v in fx["inputs"].items()}
+    run = lambda m: m(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
+                      image_only_indicator=i["image_only_indicator"])
+    new = run(build_unet(fx, dev))
+    monkeypatch.setenv("HI3D_CAT_FUSED", "0")
+    m = build_unet(fx, dev)
+    assert m.runtime(dev).cat_fused is False
+    monkeypatch.setattr(ops, "ATTN_VROW", False)
+    old = run(m)
+    assert torch.equal(new, old)
