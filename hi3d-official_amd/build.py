@@ -16,7 +16,7 @@ LIB = os.path.join(ROOT, "hi3d_hip", "libhi3d_hip.so")
 STAMP = LIB + ".stamp"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-Wno-unused-result", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage"]
+         "-Wno-unused-result", "-Wno-unused-value", "-Wno-c++20-extensions", "-Rpass-analysis=kernel-resource-usage"]
 RESOURCES = os.path.join(ROOT, "hi3d_hip", "kernel_resources.json")
 
 

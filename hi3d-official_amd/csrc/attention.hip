@@ -477,6 +477,108 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
   }
 }
 
+
+// ---- temporal attention on the matrix core, T <= 16 (round 4).  One WAVE per (clip b, pixel, head): the whole problem is
+// S^T = K Q^T (16 x 16 x 64: two v_mfma_f32_16x16x32_bf16), a softmax over <= 16 keys, O^T = V^T P^T (four
+// v_mfma_f32_16x16x16_bf16).  Layouts are chosen so that nothing is staged that does not have to be:
+//   * Q and K rows are loaded from the frame-major token tensor STRAIGHT into MFMA operand registers: lane (t = lane & 15,
+//     g = lane >> 4) holds 8 channels (d = ks * 32 + g * 8 ..) of frame t -- one 16-byte load per k-step and operand;
+//   * the swapped product leaves acc[r] = S^T[key 4g + r][query = lane & 15]: the softmax of a query is 4 registers x the 4
+//     lanes {q, q + 16, q + 32, q + 48} (two shuffles), and the packed P is ALREADY the B operand of the K = 16 MFMA;
+//   * V goes through LDS once, as four [16 keys][4 x 4 channels] images that are lane-linear for the writer (4 ds_write_b64
+//     per lane at j * 512 + lane * 8) AND for the transposing reader (ds_read_b64_tr_b16 at the same addresses): image j
+//     holds channels 16 a + 4 j + (0..3), a = 0..3, so MFMA j's output row i means channel 16 (i >> 2) + 4 j + (i & 3) and a
+//     lane ends up with 16 CONSECUTIVE channels of one query frame -- two 16-byte stores, 128 contiguous bytes per 4 lanes.
+// The round-1..3 kernel (below, still used for 16 < T <= 32) transposed V with 64 ds_write_b16 per thread (8-16-way bank
+// conflicts) and ran every product on v_dot2: 3.5 ms per stage-2 step at 3.4 TB/s; this form is bound by its q/k/v/o traffic.
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+__global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+    const unsigned short* __restrict__ v, unsigned short* __restrict__ out,
+    int B, int T, int S, int H, int ld, int ldo, float scale_log2) {
+#if __HIP_DEVICE_COMPILE__
+  __shared__ __attribute__((aligned(16))) char sV[4 * 2048];     // one 2 KiB V image set per wave
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const myV = sV + w * 2048;
+  const int t16 = lane & 15, g = lane >> 4;
+  const unsigned nitem = (unsigned)B * S * H;      // (< 2^31: checked by the host)
+  const unsigned stride = gridDim.x * 4;
+  // operand-row validity (frames >= T do not exist: zero rows; their keys are masked, their query columns are not stored)
+  const bool t_ok = t16 < T;
+  const int vkey = lane >> 2;                     // V loader: key row of this lane, channels (lane & 3) * 16 .. + 15
+  const bool v_ok = vkey < T;
+  // (the per-lane offsets below stay under 2^31: the host checks 16 frames x S x ld x 2 bytes)
+  // per-lane byte offsets inside an item's (clip, pixel, head) window: loop-invariant; rows that do not exist carry an offset
+  // beyond the descriptor's range and read as zeros (no per-load branch)
+  constexpr unsigned INV = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const long frame_pitch = (long)S * ld * 2;                                  // bytes between frames of one pixel
+  const unsigned off_qk = t_ok ? (unsigned)(t16 * frame_pitch + g * 16) : INV;
+  const unsigned off_v = v_ok ? (unsigned)(vkey * frame_pitch + (lane & 3) * 32) : INV;
+  const unsigned off_o = t_ok ? (unsigned)(t16 * (long)S * ldo * 2 + g * 32) : INV;
+  for (unsigned it = blockIdx.x * 4 + w; it < nitem; it += stride) {
+    const unsigned bp = it / (unsigned)H, h = it - bp * H;
+    const unsigned b = bp / (unsigned)S, px = bp - b * S;
+    const long base = (((long)b * T * S + px) * ld + h * 64) * 2;            // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)q + base), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)k + base), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)v + base), 0, 0x7fffffff, 0x00020000);
+    // ---- loads (all issued before the first use)
+    bf16x8 qf[2], kf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsQ, off_qk, ks * 64, 0));
+      kf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsK, off_qk, ks * 64, 0));
+    }
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsV, off_v, 0, 0);      // channels 16 a .. + 7      (a = lane & 3)
+    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsV, off_v, 16, 0);     // channels 16 a + 8 .. + 15
+    // ---- S^T = K Q^T
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], sc, 0, 0, 0);
+    // ---- V images: image j <- channels 16 a + 4 j .. + 3 of key `vkey` (8 bytes) at j * 512 + lane * 8
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    *(u32x2*)(myV + 0 * 512 + lane * 8) = u32x2{v0[0], v0[1]};
+    *(u32x2*)(myV + 1 * 512 + lane * 8) = u32x2{v0[2], v0[3]};
+    *(u32x2*)(myV + 2 * 512 + lane * 8) = u32x2{v1[0], v1[1]};
+    *(u32x2*)(myV + 3 * 512 + lane * 8) = u32x2{v1[2], v1[3]};
+    // ---- softmax over the keys of query t16: registers r (keys 4 g + r) x lanes {t16 + 16 g'}
+    float s4[4], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s4[r] = (4 * g + r < T) ? sc[r] * scale_log2 : -INFINITY;
+      mx = fmaxf(mx, s4[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float e[4], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s4[r] - mx); l += e[r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(l);
+    union { bf16x4_t v; unsigned int u[2]; } pk;
+    pk.u[0] = pack_bf16x2(e[0], e[1]); pk.u[1] = pack_bf16x2(e[2], e[3]);
+    // ---- O^T = V^T P^T: MFMA j, output row i = 4 g + r  <->  channel 16 g + 4 j + r of query t16
+    float o[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4_t*)(myV + j * 512 + lane * 8));
+      const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pk.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[j * 4 + r] = acc[r] * inv;
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)out + (((long)b * T * S + px) * ldo + h * 64) * 2), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
+                                           rsO, off_o, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(o[8], o[9]), pack_bf16x2(o[10], o[11]), pack_bf16x2(o[12], o[13]), pack_bf16x2(o[14], o[15])},
+                                           rsO, off_o, 16, 0);
+  }
+#endif
+}
+
 }  // namespace
 
 namespace {
@@ -563,6 +665,18 @@ extern "C" int hi3d_attn_temporal_d64(const void* q, const void* k, const void* 
   if (H > 65535 || B > 65535) HI3D_FAIL(HI3D_ESHAPE, "attn_temporal: grid too large");
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  // T <= 16 (every Hi3D clip shape but the 32-view one): the matrix-core kernel, one wave per (clip, pixel, head);
+  // HI3D_ATTNT_MFMA=0 selects the round-1..3 VALU kernel (A/B switch)
+  static const int mfma_env = [] { const char* e = getenv("HI3D_ATTNT_MFMA"); return e ? atoi(e) : 1; }();
+  if (mfma_env && T <= 16 && (long)B * S * H < 0x7fffffffL && 16L * S * (ldqkv > ldo ? ldqkv : ldo) * 2 < 0x7fffffffL) {
+    const long nitem = (long)B * S * H;
+    const long want = (nitem + 3) / 4;
+    const unsigned grid = (unsigned)(want < 256L * 8 * 4 ? want : 256L * 8 * 4);     // <= 32 blocks of 4 waves per CU's worth
+    hipLaunchKernelGGL(attn_temporal_mfma_kernel, dim3(grid), dim3(256), 0, s, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)v, (unsigned short*)out, B, T, S, H, ldqkv, ldo, sl2);
+    HI3D_LAUNCH_CHECK();
+    return HI3D_OK;
+  }
   static const int hfast_env = [] { const char* e = getenv("HI3D_ATTNT_HFAST"); return e ? atoi(e) : 1; }();
   const int hfast = (hfast_env && (S + 7) / 8 <= 65535) ? 1 : 0;
   if (T <= 8) {

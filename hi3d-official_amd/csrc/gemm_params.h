@@ -1,0 +1,34 @@
+// Kernel argument and internal constants shared by the GEMM translation units (gemm.hip: the tile family;
+// gemm_persist.hip: the persistent 256-row ping-pong tile).
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct GemmParams {
+  const char* A; const char* W; const float* bias; const float* rowvec;
+  const unsigned short* R1; const unsigned short* R2; const float* a1; const float* a2;
+  void* out;
+  int M, N, K, lda, ldo, ldr1, ldr2, ldrv, ldw, rpg, out_fp32, vec8;
+  int Hin, Win, Cin, Hout, Wout, stride, up2x, T, HW, pad;
+  int nbm, nbn;
+  int gn;      // tile raster: column groups of gn n-tiles, m walked inside a group (0 / >= nbn: one group = n fastest over the row)
+  int abl;     // timing ablations (HI3D_GEMM_ABL; wrong results by design): 1 = output stores dropped, 2 = no epilogue at all
+  // split-K (long-K launches with too few tiles for the chip: the 8x8 / 16x16 levels of stage 1, the ranks of a clip-parallel
+  // job): the grid is ksplit x (nbm * nbn); block (ks, tile) accumulates K steps [ks * nk_split, (ks + 1) * nk_split) -- whole
+  // channel slabs for the conv gathers, whose K walks the taps innermost -- into the fp32 partial tile ks of `out`
+  // ([ksplit][M][ldo], no bias / residual); splitk_combine_kernel sums the partials in a fixed order and applies the epilogue.
+  int ksplit, nk_split;
+  // two-source dense A (internal amode A_DENSE2): columns [0, K1) of the logical A come from A (pitch lda), columns [K1, K) from
+  // A2 (pitch lda2) -- the decoder's skip concat `th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) as two K segments
+  // of the 1x1 skip_connection GEMM instead of a materialised [M, C1 + C2] tensor
+  const char* A2; int lda2, K1;
+};
+
+constexpr int BK = 64;
+constexpr int A_CONV3X3_UP2X = 3;   // internal: HI3D_A_CONV3X3 with up2x (own instantiation: the plain gather stays lean)
+constexpr int A_DENSE2 = 4;         // internal: HI3D_A_DENSE with two K segments from two tensors (GemmParams.A2)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+}  // namespace

@@ -32,6 +32,17 @@ void want_f32(const Tensor& t, const char* name, int64_t n) {
   TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.numel() == n, name, ": contiguous fp32 [", n, "] on the GPU required");
 }
 const void* opt_ptr(const c10::optional<Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
+// every operand on the device of the first one: the launch runs under THAT device's guard and stream, a pointer of another
+// GPU would be dereferenced there (fault / peer read) instead of raising
+void same_device(const Tensor& x, std::initializer_list<const Tensor*> others, const char* name) {
+  for (const Tensor* t : others)
+    if (t && t->defined()) TORCH_CHECK(t->device() == x.device(), name, ": operands on different devices (", x.device(), " and ", t->device(), ")");
+}
+const Tensor* opt_t(const c10::optional<Tensor>& t) { return t.has_value() && t->defined() ? &*t : nullptr; }
+// the C ABI takes int32 sizes
+void fits_i32(std::initializer_list<int64_t> v, const char* name) {
+  for (int64_t x : v) TORCH_CHECK(x >= 0 && x <= 0x7fffffffLL, name, ": a size (", x, ") does not fit the int32 of the C ABI");
+}
 
 // softmax(q k^T * scale) v for head dim 64 on a fused [B*S, 3*H*64] q|k|v projection: what
 // MemoryEfficientCrossAttention.forward / CrossAttention.forward compute for self-attention (attention.py:332-336, 427-439)
@@ -40,14 +51,14 @@ Tensor self_attention(const Tensor& qkv, int64_t B, int64_t S, int64_t H, double
   const int64_t C = H * 64;
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * S && qkv.size(1) == 3 * C, "hi3d::self_attention: qkv must be [B*S, 3*H*64]");
   TORCH_CHECK(scale > 0.0, "hi3d::self_attention: scale must be > 0");
+  fits_i32({B, H, S, B * S, qkv.stride(0)}, "hi3d::self_attention");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
-  const int64_t S_pad = (S + 63) / 64 * 64, ld = qkv.stride(0);
-  Tensor vt = at::empty({B, H, 64, S_pad}, qkv.options());
+  const int64_t ld = qkv.stride(0);
   Tensor out = at::empty({B * S, C}, qkv.options());
   const char* base = (const char*)qkv.data_ptr();
-  check_rc(hi3d_transpose_v(base + 2 * C * 2, vt.data_ptr(), (int)B, (int)H, (int)S, (int)S_pad, (int)ld, stream_of(qkv)), "hi3d_transpose_v");
-  check_rc(hi3d_attn_d64(base, base + C * 2, vt.data_ptr(), out.data_ptr(), (int)B, (int)H, (int)S, (int)S, (int)ld, (int)ld, (int)S_pad, (int)C,
-                         (float)scale, stream_of(qkv)), "hi3d_attn_d64");
+  // V is read row-major from the fused projection (hi3d_attn_d64_v): no transpose pass, no V^T buffer
+  check_rc(hi3d_attn_d64_v(base, base + C * 2, base + 4 * C, out.data_ptr(), (int)B, (int)H, (int)S, (int)S, (int)ld, (int)ld, (int)ld, (int)C,
+                           (float)scale, stream_of(qkv)), "hi3d_attn_d64_v");
   return out;
 }
 
@@ -59,13 +70,11 @@ Tensor attn_d64(const Tensor& q, const Tensor& k, const Tensor& v, int64_t B, in
   TORCH_CHECK(q.size(1) >= H * 64 && k.size(1) >= H * 64 && v.size(1) >= H * 64, "hi3d::attn_d64: fewer than H*64 columns");
   TORCH_CHECK(q.device() == k.device() && q.device() == v.device(), "hi3d::attn_d64: operands on different devices");
   TORCH_CHECK(scale > 0.0, "hi3d::attn_d64: scale must be > 0");
+  fits_i32({B, H, S_q, S_kv, B * S_q, B * S_kv, q.stride(0), k.stride(0), v.stride(0)}, "hi3d::attn_d64");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
-  const int64_t S_pad = (S_kv + 63) / 64 * 64;
-  Tensor vt = at::empty({B, H, 64, S_pad}, q.options());
   Tensor out = at::empty({B * S_q, H * 64}, q.options());
-  check_rc(hi3d_transpose_v(v.data_ptr(), vt.data_ptr(), (int)B, (int)H, (int)S_kv, (int)S_pad, (int)v.stride(0), stream_of(q)), "hi3d_transpose_v");
-  check_rc(hi3d_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), (int)B, (int)H, (int)S_q, (int)S_kv, (int)q.stride(0),
-                         (int)k.stride(0), (int)S_pad, (int)(H * 64), (float)scale, stream_of(q)), "hi3d_attn_d64");
+  check_rc(hi3d_attn_d64_v(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), (int)B, (int)H, (int)S_q, (int)S_kv, (int)q.stride(0),
+                           (int)k.stride(0), (int)v.stride(0), (int)(H * 64), (float)scale, stream_of(q)), "hi3d_attn_d64_v");
   return out;
 }
 
@@ -74,6 +83,7 @@ Tensor attn_temporal(const Tensor& qkv, int64_t B, int64_t T, int64_t S, int64_t
   want_bf16_rows(qkv, "hi3d::attn_temporal qkv");
   const int64_t C = H * 64;
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * T * S && qkv.size(1) == 3 * C, "hi3d::attn_temporal: qkv must be [B*T*S, 3*H*64]");
+  fits_i32({B, T, S, H, B * T * S, qkv.stride(0)}, "hi3d::attn_temporal");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
   Tensor out = at::empty({B * T * S, C}, qkv.options());
   const char* base = (const char*)qkv.data_ptr();
@@ -87,6 +97,8 @@ Tensor groupnorm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta, 
   want_bf16_rows(x, "hi3d::groupnorm_silu x");
   TORCH_CHECK(x.is_contiguous() && x.numel() == inst * P * C, "hi3d::groupnorm_silu: x must be contiguous [inst*P, C]");
   want_f32(gamma, "hi3d::groupnorm_silu gamma", C); want_f32(beta, "hi3d::groupnorm_silu beta", C);
+  same_device(x, {&gamma, &beta}, "hi3d::groupnorm_silu");
+  fits_i32({inst, P, C}, "hi3d::groupnorm_silu");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   Tensor ws = at::empty({hi3d_gn_workspace_floats((int)inst, (int)P, (int)C)}, x.options().dtype(at::kFloat));
@@ -101,6 +113,8 @@ Tensor layernorm(const Tensor& x, const Tensor& gamma, const Tensor& beta, doubl
   TORCH_CHECK(x.is_contiguous(), "hi3d::layernorm: contiguous x required");
   const int64_t C = x.size(-1), R = x.numel() / C;
   want_f32(gamma, "hi3d::layernorm gamma", C); want_f32(beta, "hi3d::layernorm beta", C);
+  same_device(x, {&gamma, &beta}, "hi3d::layernorm");
+  fits_i32({R, C}, "hi3d::layernorm");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   check_rc(hi3d_layernorm(x.data_ptr(), y.data_ptr(), nullptr, gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr, 1, (int)R, (int)C, (float)eps,
@@ -114,7 +128,9 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.is_contiguous() && x.size(1) == w.size(1), "hi3d::linear: x [M, K], w [N, K] required");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   if (bias.has_value()) want_f32(*bias, "hi3d::linear bias", N);
-  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::linear residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == N, "hi3d::linear: residual must be [M, N]"); }
+  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::linear residual"); TORCH_CHECK(residual->dim() == 2 && residual->size(0) == M && residual->size(1) == N, "hi3d::linear: residual must be [M, N]"); }
+  same_device(x, {&w, opt_t(bias), opt_t(residual)}, "hi3d::linear");
+  fits_i32({M, N, K, x.stride(0), residual.has_value() ? residual->stride(0) : 0}, "hi3d::linear");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, N}, x.options());
   hi3d_gemm_desc d = {};
@@ -136,7 +152,9 @@ Tensor conv3x3(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bi
   TORCH_CHECK((stride == 1 || stride == 2) && !(up2x && stride == 2), "hi3d::conv3x3: stride 1 or 2; nearest-2x only with stride 1");
   const int64_t Ho = up2x ? 2 * H : (stride == 2 ? (H + 1) / 2 : H), Wo = up2x ? 2 * W : (stride == 2 ? (W + 1) / 2 : W), M = N * Ho * Wo;
   if (bias.has_value()) want_f32(*bias, "hi3d::conv3x3 bias", Cout);
-  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::conv3x3 residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == Cout, "hi3d::conv3x3: residual must be [M, Cout]"); }
+  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::conv3x3 residual"); TORCH_CHECK(residual->dim() == 2 && residual->size(0) == M && residual->size(1) == Cout, "hi3d::conv3x3: residual must be [M, Cout]"); }
+  same_device(x, {&w, opt_t(bias), opt_t(residual)}, "hi3d::conv3x3");
+  fits_i32({M, N * H * W, Cout, 9 * Cin, residual.has_value() ? residual->stride(0) : 0}, "hi3d::conv3x3");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, Cout}, x.options());
   hi3d_gemm_desc d = {};
@@ -158,7 +176,9 @@ Tensor ffn_geglu(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tens
   TORCH_CHECK(w1.is_contiguous() && w1.size(0) == 8 * C && w1.size(1) == C && w2.is_contiguous() && w2.size(0) == C && w2.size(1) == 4 * C,
               "hi3d::ffn_geglu: w1 [8C, C], w2 [C, 4C] required");
   want_f32(b1, "hi3d::ffn_geglu b1", 8 * C); want_f32(b2, "hi3d::ffn_geglu b2", C);
-  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::ffn_geglu residual"); TORCH_CHECK(residual->size(0) == M && residual->size(1) == C, "hi3d::ffn_geglu: residual must be [M, C]"); }
+  if (residual.has_value()) { want_bf16_rows(*residual, "hi3d::ffn_geglu residual"); TORCH_CHECK(residual->dim() == 2 && residual->size(0) == M && residual->size(1) == C, "hi3d::ffn_geglu: residual must be [M, C]"); }
+  same_device(x, {&w1, &b1, &w2, &b2, opt_t(residual)}, "hi3d::ffn_geglu");
+  fits_i32({M, 8 * C, residual.has_value() ? residual->stride(0) : 0}, "hi3d::ffn_geglu");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty({M, C}, x.options());
   const int ldr = residual.has_value() ? (int)residual->stride(0) : 0;

@@ -19,8 +19,10 @@ import struct
 import subprocess
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
-HIPCC = "/opt/rocm/bin/hipcc"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")       # the compiler build.py uses (same override)
+LLVM = os.environ.get("HI3D_LLVM_BIN", os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib", "llvm", "bin"))
+if not os.path.isdir(LLVM):
+    LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 ISA_CACHE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_isa")
@@ -61,9 +63,12 @@ def device_asm(hip_file, include_dirs=(), cache=True):
 def _compile_device_asm(hip_file, include_dirs=()):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-S",
-               "--cuda-device-only", "-o", out, hip_file] + [f"-I{i}" for i in include_dirs]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # (the code-generation flags of build.py's FLAGS, so the stressed ISA is the shipped one)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+               "-Wno-c++20-extensions", "-S", "--cuda-device-only", "-o", out, hip_file] + [f"-I{i}" for i in include_dirs]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed on {hip_file}:\n" + r.stdout.decode(errors="replace")[-4000:])
         return open(out).read().split("\n")
 
 

@@ -109,11 +109,14 @@ def band(M):
 def tables(kind, h, w, device):
     """Cached device-side tap tables: ((start_h, w_h), (start_w, w_w), (Ho, Wo)).
     kind 'clip224'  : kornia resize to 224 x 224, bicubic + antialias, align_corners (FrozenOpenCLIPImageEmbedder.preprocess)
+    kind 'clip224_noaa' : the same without the Gaussian pre-blur (antialias=False: plain bicubic taps)
     kind 'aes'      : bilinear to 224 x 384, columns 80:304 kept (AesEmbedder.forward)"""
     key = (kind, h, w, str(device))
     if key not in _TABLES:
         if kind == "clip224":
             Rh, Rw = kornia_axis_matrices(h, w, (224, 224))
+        elif kind == "clip224_noaa":
+            Rh, Rw = kornia_axis_matrices(h, w, (224, 224), antialias=False)
         elif kind == "aes":
             Rh = interp_matrix(h, 224, "bilinear", False)
             Rw = interp_matrix(w, 384, "bilinear", False)[80:304]

@@ -168,17 +168,21 @@ class FrozenOpenCLIPImageEmbedder(AbstractEmbModel):
         """[-1,1] image -> 224 x 224 -> [0,1] -> CLIP mean / std (reference :619-628), on the GPU in two banded passes of
         `hi3d_resample_axis` with the affine fused into the second: kornia.geometry.resize(bicubic, align_corners=True,
         antialias) is kornia 0.6.9's Gaussian pre-blur + torch's bicubic, restated in hi3d_hip/resample.py (kornia itself is
-        absent from this image: unpinned against the package).  antialias=False or an up-scale: plain bicubic taps."""
-        from hi3d_hip import ops, resample
+        absent from this image: unpinned against the package).  antialias=False (the reference accepts it) or an up-scale:
+        plain bicubic taps, no pre-blur.  Runs with x's GPU as the current device (a conditioner on cuda:1 in a process whose
+        current device is cuda:0: the kernels go to the current stream of the CURRENT device)."""
+        from hi3d_hip import ops
         size = self.model.cfg["image"]
-        mean, std = self.mean.to(x.device, torch.float32), self.std.to(x.device, torch.float32)
-        x = x.float()
-        if size != 224 or not self.antialias:
-            raise NotImplementedError("FrozenOpenCLIPImageEmbedder.preprocess: built for the shipped 224 x 224, antialias=True")
-        if tuple(x.shape[-2:]) == (size, size):                 # kornia returns the input untouched (affwarp.py: size == input_size)
-            return ((x + 1.0) / 2.0 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
-        # ((y + 1) / 2 - mean) / std  ==  y * (0.5 / std) + (0.5 - mean) / std
-        return ops.resample_image(x, "clip224", scale=(0.5 / std).contiguous(), shift=((0.5 - mean) / std).contiguous())
+        if size != 224:
+            raise NotImplementedError("FrozenOpenCLIPImageEmbedder.preprocess: built for the shipped 224 x 224 towers")
+        with torch.cuda.device(x.device):
+            mean, std = self.mean.to(x.device, torch.float32), self.std.to(x.device, torch.float32)
+            x = x.float()
+            if tuple(x.shape[-2:]) == (size, size):             # kornia returns the input untouched (affwarp.py: size == input_size)
+                return ((x + 1.0) / 2.0 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+            # ((y + 1) / 2 - mean) / std  ==  y * (0.5 / std) + (0.5 - mean) / std
+            return ops.resample_image(x, "clip224" if self.antialias else "clip224_noaa",
+                                      scale=(0.5 / std).contiguous(), shift=((0.5 - mean) / std).contiguous())
 
     def forward(self, image, no_dropout=False):
         dev = image.device if image.is_cuda else torch.device(self.device)
