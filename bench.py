@@ -142,7 +142,8 @@ def main():
         if sim is not None:
             out["legs"][f"clip_parallel_cfg2_sp{a.simulate_sp}_one_rank_simulated"] = sim
         unet = sampler = None
-    if use_dist and world > 1 and not a.no_clip_parallel:
+    # (HI3D_BENCH_FORCE_MULTI=1: run the multi-GPU legs in a ONE-rank nccl group too -- a dry run of their code on a one-GPU box)
+    if use_dist and (world > 1 or os.environ.get("HI3D_BENCH_FORCE_MULTI") == "1") and not a.no_clip_parallel:
         # second leg (not `value`): the SAME step for ONE clip spread over all GPUs -- the mapping that makes a
         # single 16/32-view clip faster: CFG pair x frame<->space groups, all collectives over RCCL
         # ... and never lose the headline line to it: a Python error is caught, and a watchdog prints the line and ends the
@@ -163,19 +164,38 @@ def main():
                                                                                  "numbers above are unaffected"})))
             except Exception as e:                        # noqa: BLE001 -- the guard is insurance, never a reason to fail
                 log(f"[bench] line guard not armed: {type(e).__name__}: {e}")
-        wd = threading.Timer(max(90.0, 40.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
+        wd = threading.Timer(max(240.0, 120.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
         wd.daemon = True
         wd.start()
+        lat = 64 if stage == 1 else 128
         try:
-            out["clip_parallel"] = clip_parallel_leg(a, unet, sampler, stage, a.views, 64 if stage == 1 else 128, dev, world, ms_per_step)
+            out["clip_parallel"] = clip_parallel_leg(a, unet, sampler.guider, stage, a.views, lat, dev, world, ms_per_step)
         except Exception as e:
             out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE config 4: "Stage-2 32 views @ 1024^2, view-parallel shard over 8 x MI355X with RCCL all-gather at VAE decode":
+        # the 32-view clip on all GPUs (CFG pair x frame<->space groups), and the sharded decode of its frames + the all-gather
+        if "error" not in out["clip_parallel"] and stage == 2 and a.views == 16:
+            try:
+                from sgm.modules.diffusionmodules.guiders import LinearPredictionGuider
+                g32 = LinearPredictionGuider(max_scale=2.0, num_frames=32, min_scale=1.0)
+                out["clip_parallel_32views"] = clip_parallel_leg(a, unet, g32, stage, 32, lat, dev, world, None,
+                                                                 steps=max(2, a.steps // 2))
+            except Exception as e:
+                out["clip_parallel_32views"] = {"error": f"{type(e).__name__}: {e}"}
+        if not any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_32views")):
+            del unet, sampler
+            unet = sampler = None
+            torch.cuda.empty_cache()
+            try:
+                out["vae_decode_sharded"] = vae_sharded_leg(a, 32 if (stage == 2 and a.views == 16) else a.views, lat, dev, world)
+            except Exception as e:
+                out["vae_decode_sharded"] = {"error": f"{type(e).__name__}: {e}"}
         wd.cancel()
         disarm()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
-        if "error" in out.get("clip_parallel", {}):
+        if any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_32views", "vae_decode_sharded")):
             sys.stdout.flush()
             os._exit(0)                  # ranks may have diverged inside the optional leg: do not wait on a teardown barrier
         torch.distributed.destroy_process_group()
@@ -427,22 +447,24 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
     return out, unet, sampler, ms_per_step
 
 
-def clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, replica_ms):
-    """One clip on all `world` GPUs: 2 (CFG halves) x world/2 (frame<->space all-to-all groups) when world is
-    even, else 1 x world.  Every rank holds the same conditioning (seed 0) and the full 4 MB latent; per step:
+def clip_parallel_leg(a, unet, guider, stage, T, lat, dev, world, replica_ms, steps=None):
+    """One clip of T views on all `world` GPUs: 2 (CFG halves) x world/2 (frame<->space all-to-all groups) when world is
+    even, else 1 x world.  Every rank holds the same conditioning (seed 0) and the full latent; per step:
     76 all-to-alls + 44 GroupNorm sum all-reduces inside each half, one all-gather of the network output."""
     import torch.distributed as dist
     from hi3d_hip import synth
     from hi3d_hip.parallel import ClipParallelStepper
+    from sgm.modules.diffusionmodules.discretizer import EDMDiscretization
+    steps = a.steps if steps is None else steps
     cfg_split = 2 if world % 2 == 0 else 1
     sp = world // cfg_split
     if T % sp or (lat // 8) ** 2 % sp:
         return {"skipped": f"frames ({T}) / lowest-level pixels ({(lat // 8) ** 2}) not divisible by sp={sp}"}
-    stepper = ClipParallelStepper(unet, sampler.guider, T, cfg=cfg_split)
+    stepper = ClipParallelStepper(unet, guider, T, cfg=cfg_split)
     x0, c, uc = synth.synth_conditioning(T, lat, lat, stage=stage, seed=0)
     c = {k: v.to(dev) for k, v in c.items()}
     uc = {k: v.to(dev) for k, v in uc.items()}
-    sigmas = sampler.discretization(sampler.num_steps, device=dev)
+    sigmas = EDMDiscretization(sigma_max=700.0)(25, device=dev)
     x = (x0.to(dev) * torch.sqrt(1.0 + sigmas[0] ** 2.0)).contiguous()
     ioi = torch.zeros(2 // cfg_split, T, device=dev)
     n = len(sigmas) - 1
@@ -451,22 +473,76 @@ def clip_parallel_leg(a, unet, sampler, stage, T, lat, dev, world, replica_ms):
     c0 = (stepper.comm.n_switches, stepper.comm.n_allreduce, stepper.comm.bytes_moved, stepper.gather_bytes)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
+    for i in range(a.warmup, a.warmup + steps):
         x = stepper.step(x, sigmas, i % n, c, uc, ioi)
     torch.cuda.synchronize(); dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     if not torch.isfinite(x).all():
         raise RuntimeError("non-finite latents in the clip-parallel leg")
-    ms = el.item() / a.steps * 1e3
-    k = a.steps
-    return {"mapping": f"cfg{cfg_split} x sp{sp}", "ms_per_step": round(ms, 2), "steps_per_s_one_clip": round(1e3 / ms, 4),
-            "speedup_vs_one_gpu_replica": round(replica_ms / ms, 3), "scaling": "strong",
+    ms = el.item() / steps * 1e3
+    k = steps
+    return {"mapping": f"cfg{cfg_split} x sp{sp}", "views": T, "steps": steps, "ms_per_step": round(ms, 2), "steps_per_s_one_clip": round(1e3 / ms, 4),
+            "speedup_vs_one_gpu_replica": None if replica_ms is None else round(replica_ms / ms, 3), "scaling": "strong",
             "all_to_all_per_step": (stepper.comm.n_switches - c0[0]) // k,
             "gn_allreduce_per_step": (stepper.comm.n_allreduce - c0[1]) // k,
             "all_to_all_bytes_sent_per_rank_per_step": (stepper.comm.bytes_moved - c0[2]) // k,
             "all_gather_bytes_received_per_rank_per_step": (stepper.gather_bytes - c0[3]) // k,
             "transport": "RCCL (torch.distributed nccl backend)"}
+
+
+def vae_sharded_leg(a, T, lat, dev, world):
+    """decode_first_stage of ONE clip of T frames sharded over all ranks + the RCCL all-gather that reassembles the clip on
+    every rank (hi3d_hip.parallel.decode_sharded; reference hand-off: sgm/models/diffusion.py:117-135; north_star: "RCCL
+    all-gather over xGMI only at VAE-decode hand-off").  Timed end to end (decode of T / world frames + gather), max over ranks."""
+    import torch.distributed as dist
+    from hi3d_hip import synth
+    from hi3d_hip.parallel import decode_sharded
+    from sgm.models.autoencoder import AutoencoderKL
+    dd = dict(attn_type="vanilla-xformers", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    ae = AutoencoderKL(embed_dim=4, ddconfig=dd)
+    synth.fill_module_(ae, 1, prefix="first_stage_model.")
+    ae = ae.to(dev)
+    z = torch.randn(T, 4, lat, lat, device=dev, generator=torch.Generator(device=dev).manual_seed(0))   # the same clip on every rank
+
+    def dec(zz):
+        return torch.cat([ae.decode(zz[i:i + 1]) for i in range(zz.shape[0])], 0)
+
+    stats = {}
+    out = decode_sharded(dec, z, stats=stats)                      # warm-up (weight re-layout, RCCL channel set-up)
+    dist.barrier(); torch.cuda.synchronize()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = decode_sharded(dec, z, stats=stats)
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # the gather alone, on the decoded frames of the last call
+    lo, hi = (T // world) * dist.get_rank(), (T // world) * (dist.get_rank() + 1)
+    mine = out[lo:hi].contiguous() if T % world == 0 else None
+    g_ms = None
+    if mine is not None:
+        buf = torch.empty_like(out)
+        dist.all_gather_into_tensor(buf, mine)
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dist.all_gather_into_tensor(buf, mine)
+        torch.cuda.synchronize()
+        g = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        g_ms = g.item() / 3 * 1e3
+    if not torch.isfinite(out).all() or out.shape[0] != T:
+        raise RuntimeError("bad output of the sharded decode")
+    ms = el.item() / reps * 1e3
+    gb = stats.get("gather_bytes", 0)
+    return {"frames": T, "resolution": lat * 8, "frames_per_rank": T / world, "ms_per_clip": round(ms, 2),
+            "frames_per_s_one_clip": round(T / ms * 1e3, 2), "all_gather_bytes_received_per_rank": gb,
+            "all_gather_ms": None if g_ms is None else round(g_ms, 3),
+            "all_gather_GBs_per_rank": None if not g_ms else round(gb / g_ms / 1e6, 1),
+            "frame_dtype": str(out.dtype).replace("torch.", ""), "transport": "RCCL all_gather_into_tensor (torch.distributed nccl backend)"}
 
 
 def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):

@@ -46,13 +46,26 @@ def frame_slice(n_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def decode_sharded(decode_fn, z, group=None):
+def _gather_into(out, mine, group):
+    """all_gather_into_tensor; a gloo group with device tensors (the one-GPU multi-process tests) stages through the host."""
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, mine.cpu().contiguous(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    return out
+
+
+def decode_sharded(decode_fn, z, group=None, stats=None):
     """Decode z[T, ...] with every rank decoding its own frame slice, then all-gather.
 
-    decode_fn(z_slice) -> images [t_local, C, H, W].  Returns [T, C, H, W] on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    decode_fn(z_slice) -> images [t_local, C, H, W].  Returns [T, C, H, W] on every rank.  The collective also runs in a
+    group of ONE rank (so the RCCL path is exercised on a single GPU).  stats (dict): receives 'gather_bytes' = the bytes this
+    rank received in the all-gather."""
+    if not dist.is_initialized():
         return decode_fn(z)
+    world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     T = z.shape[0]
     lo, hi = frame_slice(T, rank, world)
@@ -62,16 +75,16 @@ def decode_sharded(decode_fn, z, group=None):
         probe = decode_fn(z[:1])
         mine = probe[:0]
     shape = tuple(mine.shape[1:])
+    per = mine[0].numel() * mine.element_size() if mine.shape[0] else probe[0].numel() * probe.element_size()
+    if stats is not None:
+        stats["gather_bytes"] = per * (T - (hi - lo))
     if all(b - a == sizes[0][1] - sizes[0][0] for a, b in sizes):
-        out = mine.new_empty((T,) + shape)
-        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
-        return out
+        return _gather_into(mine.new_empty((T,) + shape), mine, group)
     # ragged split: pad every slice to the largest, gather, drop the padding
     tmax = max(b - a for a, b in sizes)
     pad = mine.new_zeros((tmax,) + shape)
     pad[: mine.shape[0]] = mine
-    out = mine.new_empty((world * tmax,) + shape)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    out = _gather_into(mine.new_empty((world * tmax,) + shape), pad, group)
     return torch.cat([out[r * tmax: r * tmax + (b - a)] for r, (a, b) in enumerate(sizes)], 0)
 
 
@@ -131,6 +144,7 @@ class FrameSpaceGroup:
         self.t_lo = self.rank * self.Tl
         self.bytes_moved = self.n_switches = self.n_allreduce = 0
         self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self._recv = {}         # (shape, dtype, device) -> [2 receive buffers, next index]: see _a2a
 
     def local_frames(self, B):
         """indices (into the (b t) frame axis of the whole batch) of this rank's frames"""
@@ -141,10 +155,24 @@ class FrameSpaceGroup:
             raise ValueError(f"pixels per frame ({S}) must be a multiple of the frame-parallel degree ({self.world})")
         return S // self.world
 
+    def _recv_buffer(self, send):
+        """Persistent receive buffers, two per exchange shape used alternately: a step makes 76 exchanges of ~6 shapes, and a
+        fresh allocation per exchange (round 3) put an allocator call -- and, under RCCL, a stream-recorded block that the
+        caching allocator cannot recycle until the collective's stream is done -- in front of every one.  Two, because the
+        result of an exchange is consumed (unpacked by the next kernel) before the second-next exchange of the same shape
+        starts on the same stream: frames_to_space -> ... -> space_to_frames alternate shapes, and the unpack of exchange k
+        is stream-ordered before the pack of exchange k + 1."""
+        key = (tuple(send.shape), send.dtype, send.device)
+        ent = self._recv.get(key)
+        if ent is None:
+            ent = self._recv[key] = [[torch.empty_like(send), torch.empty_like(send)], 0]
+        ent[1] ^= 1
+        return ent[0][ent[1]]
+
     def _a2a(self, send):
-        recv = torch.empty_like(send)
         if self.world == 1:
             return send
+        recv = self._recv_buffer(send)
         if send.is_cuda and self._host_staged:          # test-only route: gloo has no device all-to-all
             s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
             dist.all_to_all_single(r, s, group=self.group)
@@ -282,7 +310,10 @@ class ClipParallelStepper:
                     cc = (uc, c)[self.half]["concat"][lo:hi].to(dev, torch.float32)
                 else:
                     cc = torch.cat((uc["concat"][lo:hi], c["concat"][lo:hi]), 0).to(dev, torch.float32)
-            self._clip = (key, pick("crossattn"), pick("vector"), cc, (c, uc))     # refs held: ids stay unique
+            # cfg == 1: the two halves are sliced ONCE here (step() used to slice per call: fresh view objects every step, so
+            # the step-buffer cache keyed on their identity never hit and the buffers were rebuilt every step -- ADVICE r3)
+            halves = (None, None) if cc is None else ((cc, cc) if self.cfg == 2 else (cc[:self.comm.Tl], cc[self.comm.Tl:]))
+            self._clip = (key, pick("crossattn"), pick("vector"), cc, (c, uc), halves)     # refs held: ids stay unique
         return self._clip[1:4]
 
     def _buffers(self, x, cc_u, cc_c, dev):
@@ -313,12 +344,7 @@ class ClipParallelStepper:
             st = rt.clip_consts(ctx, y, image_only_indicator, B * T, T)
             # step head on HIP kernels (no ATen elementwise / cat): x * c_in into the 4 latent channels of the persistent token
             # buffer of this rank's frames, c_noise per batch row, sigma read on the device
-            if cc is None:
-                cu_l = cc_l = None
-            elif self.cfg == 2:
-                cu_l = cc_l = cc                                                      # this rank's half only (both slots: one is read)
-            else:
-                cu_l, cc_l = cc[:Tl], cc[Tl:]
+            cu_l, cc_l = self._clip[5]          # (cfg == 2: this rank's half in both slots, one is read)
             xl, tok2, sig, tv_l, tv_full = self._buffers(x, cu_l, cc_l, dev)
             sig.copy_(sigmas[i:i + 2])
             xl.copy_(x[lo:lo + Tl])

@@ -28,12 +28,23 @@ def _denoiser_fn(model, T, device):
     return denoiser
 
 
+def _decode(model, latents, decode_group):
+    """decode_first_stage of the clip (sgm/models/diffusion.py:117-135).  decode_group = a torch.distributed process group
+    (or True: the default group) over which the FRAMES are sharded: every rank decodes T / world frames with the HIP VAE and
+    ONE all-gather (RCCL on the GPUs) reassembles the clip on every rank -- north_star's "RCCL all-gather at VAE-decode
+    hand-off" (hi3d_hip.parallel.decode_sharded).  None: this rank decodes all frames."""
+    if decode_group is None or decode_group is False:
+        return model.decode_first_stage(latents)
+    from .parallel import decode_sharded
+    return decode_sharded(model.decode_first_stage, latents, None if decode_group is True else decode_group)
+
+
 @torch.no_grad()
-def stage1_denoise(model, c, uc, T, h, w, noise=None, decode=True):
+def stage1_denoise(model, c, uc, T, h, w, noise=None, decode=True, decode_group=None):
     dev = model.device
     x = torch.randn((T, 4, h, w), device=dev) if noise is None else noise.to(dev, torch.float32).clone()
     samples = model.sampler(_denoiser_fn(model, T, dev), x, cond=c, uc=uc)
-    return model.decode_first_stage(samples) if decode else samples
+    return _decode(model, samples, decode_group) if decode else samples
 
 
 def v02_alpha(i, num_steps, alpha_pow=40.0):
@@ -42,8 +53,9 @@ def v02_alpha(i, num_steps, alpha_pow=40.0):
 
 
 @torch.no_grad()
-def stage2_refine(model, frames, c, uc, init_noise=None, encode_noise=None, decode=True, z_frames=None):
-    """frames: [3, T, H, W] stage-1 video in [-1, 1] (or pass z_frames [T,4,h,w] directly)."""
+def stage2_refine(model, frames, c, uc, init_noise=None, encode_noise=None, decode=True, z_frames=None, decode_group=None):
+    """frames: [3, T, H, W] stage-1 video in [-1, 1] (or pass z_frames [T,4,h,w] directly).
+    decode_group: shard the final VAE decode over a process group (see _decode)."""
     dev = model.device
     sampler = model.sampler
     sigmas = sampler.discretization(sampler.num_steps, device=dev)
@@ -65,4 +77,4 @@ def stage2_refine(model, frames, c, uc, init_noise=None, encode_noise=None, deco
     for i in sampler.get_sigma_gen(num_sigmas):
         ops.v02_blend(latents, init, z_frames, v02_alpha(i, sampler.num_steps), sig_host[i])
         latents = sampler.step_call(den, latents, i, s_in, sigmas, num_sigmas, c, uc).contiguous()
-    return model.decode_first_stage(latents) if decode else latents
+    return _decode(model, latents, decode_group) if decode else latents
