@@ -52,6 +52,7 @@ def unet_cfg(stage, mc=320):
 STEP_TFLOP = {1: 40.61, 2: 209.47}
 STEP_TFLOP_EXECUTED = {1: 39.3, 2: 202.7}
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0       # dense MFMA fp8 (MX-scaled K = 128 forms), same guide
 PEAK_HBM_GBS = 8000.0
 
 
@@ -431,8 +432,16 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
             if fam not in summ:
                 continue
             d = summ[fam]
-            out["attention_mfma"] = {"achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            a_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["attention_mfma"] = {"kernel": fam, "achieved": round(a_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(a_tf / PEAK_BF16_TFLOPS, 4), "peak_is": "dense bf16 MFMA"}
+            if fam != "attn_d64":
+                # the fp8 kernels run their matrix products at the fp8 rate: state the fraction of THAT peak too (fp8qk: only
+                # the score product -- half the FLOPs -- is fp8, so its ceiling is the harmonic mix 2 / (1/2.5 + 1/5) PF)
+                pk = PEAK_FP8_TFLOPS if fam == "attn_d64_fp8" else 2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_FP8_TFLOPS)
+                out["attention_mfma"].update(frac_fp8_peak=round(a_tf / pk, 4), fp8_peak=round(pk, 1),
+                                             fp8_peak_is="dense fp8 MFMA 5 PF" if fam == "attn_d64_fp8" else
+                                             "score product at the 5 PF fp8 rate, P V at the 2.5 PF bf16 rate")
         for fam in ("groupnorm_silu", "layernorm"):
             if fam in summ:
                 d = summ[fam]
@@ -546,18 +555,20 @@ def vae_sharded_leg(a, T, lat, dev, world):
 
 
 def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
-    """Oracle (oracle/hi3d_oracle.py, fp32 torch CPU kernels = the reference's CPU path
-    restated) timed on this box's host cores on a bounded sample of the same step: the
-    full-width UNet at T=8, latent 16x16 (10-20 s of CPU work), extrapolated to the full step by
-    executed FLOPs."""
+    """Oracle (oracle/hi3d_oracle.py, fp32 torch CPU kernels = the reference's CPU path restated) timed on this box's host cores
+    on a bounded sample of the same step: ONE full-width forward at T = 16, latent 32 x 32 (the clip length of the headline, 1/16
+    of its pixels: ~4.4 executed TFLOP, 10 - 40 s on the box's cores) after a small warm-up call that touches the 6 GB of
+    weights; extrapolated to the full step by executed FLOPs.  (Rounds 1-3 sampled T = 8 at latent 16 x 16 -- 1.1 TFLOP, too
+    small to keep 128 threads busy: it under-stated the CPU about 3x per core against the reference-class probe of
+    BASELINE.md section 3, which is quoted beside it.)"""
     from hi3d_hip import ops
     from oracle import hi3d_oracle as O
-    T, hw = 8, 16
+    T, hw = 16, 32
     g = torch.Generator().manual_seed(0)
-    x = torch.randn((2 * T, cfg["in_channels"], hw, hw), generator=g)
-    ts = torch.full((2 * T,), 0.25 * 1.5)
-    ctx, y = torch.randn((2, 1, 1024), generator=g), torch.randn((2, cfg["adm_in_channels"]), generator=g)
-    ioi = torch.zeros(2, T)
+    x = torch.randn((T, cfg["in_channels"], hw, hw), generator=g)
+    ts = torch.full((T,), 0.25 * 1.5)
+    ctx, y = torch.randn((1, 1, 1024), generator=g), torch.randn((1, cfg["adm_in_channels"]), generator=g)
+    ioi = torch.zeros(1, T)
     # executed FLOPs of the sample, counted by the same per-launch formulae as the GPU path
     prof = ops.Profiler(); ops.PROFILER = prof
     unet(x.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=T, image_only_indicator=ioi.to(dev))
@@ -566,21 +577,24 @@ def cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf):
     threads = torch.get_num_threads()
     times = []
     with torch.no_grad():
-        O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")      # warm-up: first touch of 6 GB of weights
-        for _ in range(3):
+        # warm-up: first touch of the 6 GB of weights, thread pool start (T = 4, latent 8 x 8)
+        O.video_unet(cpu_sd, cfg, x[:4, :, :8, :8].contiguous(), ts[:4], ctx, y, 4, ioi[:, :4], prefix="model.diffusion_model.")
+        for _ in range(2):
             t0 = time.perf_counter()
             O.video_unet(cpu_sd, cfg, x, ts, ctx, y, T, ioi, prefix="model.diffusion_model.")
             times.append(time.perf_counter() - t0)
-            if sum(times) > 40.0:
+            if sum(times) > 25.0:
                 break
-    dt = sorted(times)[len(times) // 2]          # median of the repeats
+    dt = min(times)
     cpu_tflops = sample_flops / dt / 1e12
     full = step_flops_exec if step_flops_exec else step_tf * 1e12
     return {"value": round(cpu_tflops * 1e12 / full, 6), "unit": "steps/s", "cores": threads, "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"oracle fp32 UNet forward, full width, T=8, latent 16x16 ({sample_flops / 1e12:.2f} TFLOP; median of "
-                      f"{len(times)} runs after one warm-up = {dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {threads} torch "
+            "host_cpus": os.cpu_count(), "tflops": round(cpu_tflops, 4),
+            "sample": f"oracle fp32 UNet forward, full width, T=16, latent 32x32 ({sample_flops / 1e12:.2f} TFLOP executed; best of "
+                      f"{len(times)} run(s) after a small warm-up call = {dt:.1f}s = {cpu_tflops:.3f} TFLOP/s on {threads} torch "
                       f"threads, {os.cpu_count()} host CPUs), extrapolated to the {full / 1e12:.1f} TFLOP executed per full step",
+            "reference_class_probe": "BASELINE.md section 3: the reference's own VideoUNet classes, full stage-1 size, 0.34 TFLOP/s on the "
+                                     "8 cores of the survey container (not re-run here: /root/reference does not travel to the GPU box)",
             "seconds": round(dt, 2), "runs_s": [round(t, 2) for t in times]}
 
 

@@ -560,3 +560,36 @@ def test_abi_argument_validation_needs_no_gpu():
     assert lib.hi3d_gemm_bf16(C.byref(d), None) == ESHAPE and "multiple of 64" in lib.hi3d_last_error().decode()
     d.K, d.lda, d.amode, d.Cin = 576, 576, L.A_CONV3X3, 60
     assert lib.hi3d_gemm_bf16(C.byref(d), None) == ESHAPE and "conv3x3" in lib.hi3d_last_error().decode()
+
+
+@pytest.mark.parametrize("name", ["inference-v01.yaml", "inference-v02.yaml"])
+def test_reference_yaml_loads_verbatim(name, tmp_path):
+    """The drop-in claim on the reference's OWN files: /root/reference/configs/inference-v0{1,2}.yaml, byte
+    for byte, through vtdm.model.create_model (the `target:` registry of sgm/util.py:168-185 resolving to this package's
+    mirrors).  Only the widths are reduced -- in a copy, by key, nothing added or removed -- so the test stays cheap on CPU;
+    skipped where the reference tree is absent (the GPU box)."""
+    import yaml
+    from vtdm.model import create_model
+    src = os.path.join("/root/reference/configs", name)
+    if not os.path.exists(src):
+        pytest.skip("reference tree not present")
+    y = yaml.safe_load(open(src))
+    y0 = yaml.safe_load(open(src))
+    y["model"]["params"]["network_config"]["params"]["model_channels"] = 64
+    y["model"]["params"]["first_stage_config"]["params"]["ddconfig"]["ch"] = 64
+    from conftest import shrink_conditioner
+    try:
+        y = shrink_conditioner(y)
+    except KeyError:
+        pass
+    p = tmp_path / name
+    yaml.safe_dump(y, open(p, "w"))
+    m = create_model(str(p))
+    net = y0["model"]["params"]["network_config"]["params"]
+    assert m.model.diffusion_model.cfg["in_channels"] == net["in_channels"]
+    assert m.sampler.num_steps == y0["model"]["params"]["sampler_config"]["params"]["num_steps"]
+    assert m.num_samples == y0["model"]["params"]["num_samples"]
+    keys = list(m.state_dict())
+    assert any(k.startswith("model.diffusion_model.input_blocks.0.0.weight") for k in keys)
+    assert any(k.startswith("first_stage_model.decoder.conv_in.weight") for k in keys)
+    assert len(m.conditioner.embedders) == len(y0["model"]["params"]["conditioner_config"]["params"]["emb_models"])

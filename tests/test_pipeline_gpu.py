@@ -10,6 +10,7 @@ import yaml
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def test_stage1_clip_create_model_sample_decode(dev):
@@ -145,3 +146,79 @@ def test_stage2_clip_from_yaml_conditioner_encode_refine_decode(dev):
     lat_rel, img_rel = r(lat, lat_ref), r(img, img_ref)
     print(f"stage2 e2e: latents rel {lat_rel:.4f} cos {cosf(lat, lat_ref):.6f}  image rel {img_rel:.4f} cos {cosf(img, img_ref):.6f}")
     assert lat_rel < 6e-2 and cosf(lat, lat_ref) > 0.999 and img_rel < 8e-2 and cosf(img, img_ref) > 0.998
+
+
+# ------------------------------------------------------------------ f4: checkpoint -> runtime, re-layout cache
+def _yaml_with_unet(cfg, tmp_path):
+    """configs/inference-v01.yaml with the network_config of a golden fixture (and reduced CLIP towers): what
+    pipeline_i2v_eval_v01.py hands to vtdm.model.create_model"""
+    import yaml
+    from conftest import shrink_conditioner
+    y = shrink_conditioner(yaml.safe_load(open(os.path.join(ROOT, "hi3d-official_amd", "configs", "inference-v01.yaml"))))
+    y["model"]["params"]["network_config"]["params"] = dict(cfg)
+    p = tmp_path / "cfg.yaml"
+    yaml.safe_dump(y, open(p, "w"))
+    return str(p)
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_s1", "unet_s1_lat16"])
+def test_deepspeed_checkpoint_to_runtime_matches_reference_golden(dev, tmp_path, name):
+    """How first_stage.pt / second_stage.pt reach the kernels (vtdm/vtdm_gen_v01.py:30-56, pipeline_i2v_eval_v01.py:34-44):
+    a DeepSpeed ZeRO dump {'module': {'module.<key>': tensor}} on disk -> create_model(yaml) -> init_from_ckpt -> the HIP
+    runtime packs what was LOADED -> forward == the golden the reference classes produced with the same weights.  At the
+    tiny width and at the full stage-1 widths (1.5 B parameters, a 6 GB file)."""
+    from hi3d_hip import synth
+    from vtdm.model import create_model
+    fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    model = create_model(_yaml_with_unet(fx["cfg"], tmp_path))
+    pre = fx["key_prefix"]
+    sd = {"module." + pre + k: synth.synth_tensor(pre + k, v.shape, fx["weight_seed"])
+          for k, v in model.model.diffusion_model.state_dict().items() if v.dtype.is_floating_point}
+    path = str(tmp_path / "stage.pt")
+    torch.save({"module": sd, "dp_world_size": 8, "global_steps": 1}, path)
+    del sd
+    before = next(iter(model.model.diffusion_model.parameters())).detach().clone()
+    model.init_from_ckpt(path)
+    os.remove(path)
+    assert not torch.equal(before, next(iter(model.model.diffusion_model.parameters())).detach())
+    unet = model.model.diffusion_model.to(dev)
+    i = {k: v.to(dev) for k, v in fx["inputs"].items()}
+    out = unet(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
+               image_only_indicator=i["image_only_indicator"])
+    a, b = out.float().cpu().flatten(), fx["output"].float().flatten()
+    rel = ((a - b).abs().max() / b.abs().max()).item()
+    cosv = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    print(f"{name} through a DeepSpeed checkpoint: rel {rel:.4f} cos {cosv:.6f}")
+    assert rel < 4e-2 and cosv > 0.9995
+
+
+def test_pack_cache_cold_and_warm_are_bit_identical(dev, tmp_path, monkeypatch):
+    """HI3D_PACK_CACHE (hi3d_hip/relayout_cache.py; runtime_unet.py:91-106): the first runtime built from a checkpoint packs the
+    weights and writes the cache, a second one (a new process in real use) finds it by the fingerprint of the weights and loads
+    it -- same kernels' inputs bit for bit, so the forward is bit-identical; a DIFFERENT checkpoint misses the cache."""
+    from conftest import synth_unet
+    fx = torch.load(os.path.join(GOLD, "unet_s1_lat16.pt"), weights_only=False)
+    monkeypatch.setenv("HI3D_PACK_CACHE", str(tmp_path / "packcache"))
+    i = {k: v.to(dev) for k, v in fx["inputs"].items()}
+    run = lambda m: m(i["x"], i["timesteps"], context=i["context"], y=i["y"], num_video_frames=fx["T"],
+                      image_only_indicator=i["image_only_indicator"])
+    cold = synth_unet(fx, dev)
+    out_cold = run(cold)
+    assert cold.runtime(dev).packed_from_cache is False
+    files = os.listdir(tmp_path / "packcache")
+    assert len(files) == 1 and files[0].startswith("unet-packed-")
+    warm = synth_unet(fx, dev)
+    out_warm = run(warm)
+    assert warm.runtime(dev).packed_from_cache is True
+    assert torch.equal(out_cold, out_warm)
+    monkeypatch.delenv("HI3D_PACK_CACHE")
+    plain = synth_unet(fx, dev)
+    assert torch.equal(run(plain), out_cold) and plain.runtime(dev).packed_from_cache is False
+    # one weight changed -> another fingerprint -> packed again, second file
+    monkeypatch.setenv("HI3D_PACK_CACHE", str(tmp_path / "packcache"))
+    other = synth_unet(fx, dev)
+    with torch.no_grad():
+        other.get_parameter("out.2.weight").mul_(1.5)
+    out_other = run(other)
+    assert other.runtime(dev).packed_from_cache is False and len(os.listdir(tmp_path / "packcache")) == 2
+    assert not torch.equal(out_other, out_cold)
