@@ -19,6 +19,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 #include "gemm_params.h"
 
@@ -852,9 +853,27 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const CombineParams
   else *(u32x2*)((unsigned short*)c.out + (long)m * c.ldo + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 
-// caller-provided scratch for the fp32 partial tiles, one per device (hi3d_gemm_set_workspace); no workspace = no split-K
-struct GemmWorkspace { void* ptr; long bytes; };
-GemmWorkspace g_ws[HI3D_MAX_DEVICES] = {};
+// Caller-provided scratch for the fp32 partial tiles; no workspace = no split-K.  A scratch buffer belongs to ONE stream:
+// two split-K launches in flight on two streams of a device would write the same partial tiles.  So the table is
+// keyed by (device, stream): hi3d_gemm_set_workspace_for_stream registers a buffer for a stream (also a capture stream: the
+// pointer is baked into the captured graph), and the stream-less hi3d_gemm_set_workspace registers one that the FIRST stream
+// to split with it claims -- a launch on any other stream finds no workspace and simply does not split (same result up to
+// the fp32 summation order, never a race).
+struct GemmWorkspace { void* ptr; long bytes; hipStream_t stream; bool any_stream, claimed; };
+constexpr int WS_SLOTS = 8;                       // per device: slot 0 = the stream-less registration
+GemmWorkspace g_ws[HI3D_MAX_DEVICES][WS_SLOTS] = {};
+std::mutex g_ws_mu;
+// the workspace `stream` may use on `dev` (claims the stream-less one for it on first use), or nullptr
+GemmWorkspace* ws_for(int dev, hipStream_t stream, bool claim) {
+  if (dev < 0 || dev >= HI3D_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 1; i < WS_SLOTS; ++i)
+    if (g_ws[dev][i].ptr && g_ws[dev][i].stream == stream) return &g_ws[dev][i];
+  GemmWorkspace& w = g_ws[dev][0];
+  if (!w.ptr) return nullptr;
+  if (!w.claimed) { if (claim) { w.claimed = true; w.stream = stream; } return &w; }
+  return w.stream == stream ? &w : nullptr;
+}
 
 // K split of a launch with `tiles` 128-row tiles: as many splits (<= 8) as keep tiles * S within the chip's 512 block slots
 // (256 CUs x 2 resident blocks), each at least 8 K steps long and a whole number of `units` (K steps for dense A, 64-channel
@@ -872,7 +891,22 @@ extern "C" int hi3d_gemm_set_workspace(void* ptr, int64_t bytes) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HI3D_MAX_DEVICES) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: no current device");
   if (bytes < 0 || (ptr == nullptr) != (bytes == 0) || ((uintptr_t)ptr & 15)) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: bad pointer / size");
-  g_ws[dev] = GemmWorkspace{ptr, (long)bytes};
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws[dev][0] = GemmWorkspace{ptr, (long)bytes, nullptr, true, false};
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_gemm_set_workspace_for_stream(void* ptr, int64_t bytes, void* stream) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HI3D_MAX_DEVICES) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: no current device");
+  if (bytes < 0 || (ptr == nullptr) != (bytes == 0) || ((uintptr_t)ptr & 15)) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace: bad pointer / size");
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  int slot = -1;
+  for (int i = 1; i < WS_SLOTS; ++i) if (g_ws[dev][i].ptr && g_ws[dev][i].stream == (hipStream_t)stream) slot = i;   // replace / withdraw
+  if (slot < 0) for (int i = 1; i < WS_SLOTS && slot < 0; ++i) if (!g_ws[dev][i].ptr) slot = i;
+  if (!ptr) { if (slot > 0) g_ws[dev][slot] = GemmWorkspace{}; return HI3D_OK; }
+  if (slot < 0) HI3D_FAIL(HI3D_EINVAL, "gemm_set_workspace_for_stream: all per-stream slots of this device are taken");
+  g_ws[dev][slot] = GemmWorkspace{ptr, (long)bytes, (hipStream_t)stream, false, true};
   return HI3D_OK;
 }
 
@@ -972,16 +1006,17 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // is cut along K into `ksplit` blocks per tile in ONE grid; fp32 partial tiles go to the caller's workspace
   // (hi3d_gemm_set_workspace) and splitk_combine_kernel applies the epilogue.  HI3D_GEMM_SPLITK=0 disables, =S forces S.
   int ksplit = 1;
+  GemmWorkspace* ws = nullptr;
   if ((variant == 0 || variant == 2) && (tile == 128 || tile == 160) && d->epi == HI3D_EPI_AFFINE && d->K >= 2048 &&
       (long)d->M * d->N >= (1L << 18) && (((uintptr_t)d->out | (uintptr_t)d->R1 | (uintptr_t)d->R2) & 7) == 0) {
     int dev = -1;
     static const int force = [] { const char* e = getenv("HI3D_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
-    if (force != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < HI3D_MAX_DEVICES && g_ws[dev].ptr) {
+    if (force != 0 && hipGetDevice(&dev) == hipSuccess && (ws = ws_for(dev, (hipStream_t)stream, g_capture == nullptr)) != nullptr) {
       const int taps = d->amode == HI3D_A_CONV3X3 ? 9 : d->amode == HI3D_A_CONVT3 ? 3 : 1;
       const int units = d->K / BK / taps;
       const long part = (long)d->M * d->N * 4, tiles = (long)((d->M + 127) / 128) * ((d->N + tile - 1) / tile);
-      ksplit = splitk_choose(tiles, units, taps, part, g_ws[dev].bytes);
-      if (force > 1 && units % force == 0 && part * force <= g_ws[dev].bytes) ksplit = force;
+      ksplit = splitk_choose(tiles, units, taps, part, ws->bytes);
+      if (force > 1 && units % force == 0 && part * force <= ws->bytes) ksplit = force;
       if (ksplit > 1) variant = 0;                 // (the 256-row tile of variant 2 would halve the tile count again)
     }
   }
@@ -1011,11 +1046,11 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     hipGetDevice(&dev);
     GemmParams q = p;
     q.ksplit = ksplit; q.nk_split = d->K / BK / ksplit;
-    q.out = g_ws[dev].ptr; q.out_fp32 = 1; q.ldo = d->N; q.vec8 = d->N % 8 == 0;
+    q.out = ws->ptr; q.out_fp32 = 1; q.ldo = d->N; q.vec8 = d->N % 8 == 0;
     q.bias = nullptr; q.rowvec = nullptr; q.R1 = nullptr; q.R2 = nullptr; q.a1 = nullptr; q.a2 = nullptr;
     const int rc = tile == 160 ? dispatch<2, 5, 2>(q, amode, d->epi, s) : dispatch<2, 4, 2>(q, amode, d->epi, s);
     if (rc || g_capture) return rc;
-    CombineParams c{(const float*)g_ws[dev].ptr, d->bias, d->rowvec, (const unsigned short*)d->R1, (const unsigned short*)d->R2,
+    CombineParams c{(const float*)ws->ptr, d->bias, d->rowvec, (const unsigned short*)d->R1, (const unsigned short*)d->R2,
                     d->a1, d->a2, d->out, d->M, d->N, ksplit, d->ldo, d->ldr1, d->ldr2, p.ldrv, d->rows_per_group, d->out_fp32};
     const long nthr = (long)d->M * (d->N / 4);
     hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, c);
@@ -1064,16 +1099,20 @@ extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
 // debug aid: what hi3d_gemm_bf16(d) would launch.  params_out receives the kernel argument (struct GemmParams, at most 512
 // bytes); info[0..9] = {bytes of the argument, grid, block, dynamic LDS bytes, WM, NT, NS, AMODE, EPI, PP} -- the template
 // arguments name the instantiation gemm_bf16_kernel<WM, NT, NS, AMODE, EPI, PP>.  Nothing is launched.
-extern "C" int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info) {
+extern "C" int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* stream, void* params_out, int32_t* info) {
   if (!params_out || !info) HI3D_FAIL(HI3D_EINVAL, "debug_gemm_launch_info: null pointer");
   static_assert(sizeof(GemmParams) <= 512, "GemmParams grew beyond the debug buffer");
   GemmCapture c;
   g_capture = &c;
-  const int rc = hi3d_gemm_bf16(d, nullptr);
+  const int rc = hi3d_gemm_bf16(d, stream);        // (the stream decides which split-K scratch -- if any -- the launch would use)
   g_capture = nullptr;
   if (rc) return rc;
   memcpy(params_out, &c.p, sizeof(GemmParams));
   const int v[10] = {(int)sizeof(GemmParams), c.grid, c.block, c.smem, c.WM, c.NT, c.NS, c.AMODE, c.EPI, c.PP};
   for (int i = 0; i < 10; ++i) info[i] = v[i];
   return HI3D_OK;
+}
+
+extern "C" int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info) {
+  return hi3d_debug_gemm_launch_info_on(d, nullptr, params_out, info);
 }

@@ -197,7 +197,8 @@ def gemm_launch_info(desc):
     lib = _l.load()
     buf = C.create_string_buffer(512)
     info = (C.c_int32 * 10)()
-    _l.check(lib.hi3d_debug_gemm_launch_info(desc, buf, info), "hi3d_debug_gemm_launch_info")
+    import torch
+    _l.check(lib.hi3d_debug_gemm_launch_info_on(desc, torch.cuda.current_stream().cuda_stream, buf, info), "hi3d_debug_gemm_launch_info_on")
     nbytes, grid, block, smem, WM, NT, NS, AMODE, EPI, PP = list(info)
     return gemm_symbol(WM, NT, NS, AMODE, EPI, PP), grid, block, smem, buf.raw[:nbytes]
 

@@ -109,6 +109,7 @@ class FusedStepper:
         self._concat = None            # (concat_c, version, concat_uc, version): what self.tok currently holds
         self.merged = {}               # key -> (c tensor, ver, uc tensor, ver, cat(uc, c))
         self.graph = None
+        self._cap_stream = None
         self.eager_steps = 0
         self.use_graph = os.environ.get("HI3D_STEP_GRAPH", "1") != "0"
 
@@ -163,7 +164,12 @@ class FusedStepper:
                 # two eager steps have raised every kernel's LDS limit and filled the lazy caches
                 # (frame-position embeddings); shapes and pointers are static from here on
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # captured on a stream of our own whose split-K scratch is registered BEFORE the capture (the graph bakes the
+                # pointer in; a scratch buffer belongs to one stream: hi3d_gemm_set_workspace_for_stream)
+                if self._cap_stream is None:
+                    self._cap_stream = torch.cuda.Stream(device=self.rt.dev)
+                    ops._ensure_gemm_workspace(self.rt.dev, self._cap_stream)
+                with torch.cuda.graph(g, stream=self._cap_stream):
                     self._body(st)
                 self.graph = g
                 g.replay()

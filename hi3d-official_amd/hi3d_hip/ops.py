@@ -113,23 +113,28 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
     return d, out
 
 
-_GEMM_WS = {}        # device index -> the split-K scratch registered with the library (held for the life of the process)
+_GEMM_WS = {}        # (device index, stream handle) -> the split-K scratch registered for that stream (held for the life of the process)
 
 
-def _ensure_gemm_workspace(dev):
-    """Register hi3d_gemm_bf16's split-K scratch on `dev` once (HI3D_GEMM_WS_MB, default 96 MiB = 8 partial tiles of the
-    largest launch that is ever split; 0 = none).  Not during a graph capture: the allocation would belong to the capture's
-    pool -- the eager steps that precede every capture in this package have registered it by then."""
+def _ensure_gemm_workspace(dev, stream=None):
+    """Register hi3d_gemm_bf16's split-K scratch for (`dev`, the current stream -- or `stream`) once (HI3D_GEMM_WS_MB, default
+    96 MiB = 8 partial tiles of the largest launch that is ever split; 0 = none).  One buffer PER STREAM: two split-K GEMMs in
+    flight on two streams of a GPU must not share partial tiles (hi3d_gemm_set_workspace_for_stream).  Not during a graph
+    capture: the allocation would belong to the capture's pool -- fused_step registers its capture stream before it captures."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx in _GEMM_WS:
+    handle = (torch.cuda.current_stream(idx) if stream is None else stream).cuda_stream
+    if (idx, handle) in _GEMM_WS:
         return
     if torch.cuda.is_current_stream_capturing():
         return
     mb = int(os.environ.get("HI3D_GEMM_WS_MB", "96"))
     ws = torch.empty(mb << 20, dtype=torch.uint8, device=dev) if mb > 0 else None
-    with torch.cuda.device(idx):
-        _l.check(_lib.hi3d_gemm_set_workspace(_p(ws), mb << 20 if ws is not None else 0), "hi3d_gemm_set_workspace")
-    _GEMM_WS[idx] = ws
+    if ws is not None:
+        with torch.cuda.device(idx):
+            rc = _lib.hi3d_gemm_set_workspace_for_stream(_p(ws), mb << 20, handle)
+        if rc != 0:          # all per-stream slots taken (a process cycling through many streams): this stream does not split
+            ws = None
+    _GEMM_WS[(idx, handle)] = ws
 
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,

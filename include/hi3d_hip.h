@@ -116,12 +116,20 @@ int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
  * every level on the ranks of a clip-parallel job -- are cut along K inside ONE grid; the fp32 partial tiles
  * ([S][M][N], S <= 8) go here and a second kernel sums them in a fixed order and applies the epilogue.  `bytes` bounds
  * S * M * N * 4; ptr = NULL / bytes = 0 withdraws the workspace (no split-K: same results up to fp32 summation order).  The
- * buffer must outlive every hi3d_gemm_bf16 call on the device and is used by one stream at a time. */
+ * buffer must outlive every hi3d_gemm_bf16 call on the device.  It is claimed by the first stream that splits with it: a
+ * launch on any other stream does not split (round 4: enforced, see hi3d_gemm_set_workspace_for_stream). */
 int hi3d_gemm_set_workspace(void* ptr, int64_t bytes);
+/* The same, bound to ONE stream (round 4): split-K launches on `stream` of the current device use this buffer, launches on
+ * other streams never do (they use their own registration, or the stream-less one above if they were the first to claim it,
+ * or do not split) -- two GEMMs in flight on two streams cannot share partial tiles.  Register the stream a HIP graph is
+ * CAPTURED on before capturing (the pointer is baked into the graph).  Up to 7 streams per device; ptr = NULL withdraws. */
+int hi3d_gemm_set_workspace_for_stream(void* ptr, int64_t bytes, void* stream);
 /* debug aid (ISA-level timing stress, hi3d_hip/devtools/isa_stress.py): the launch hi3d_gemm_bf16(d) WOULD make, not made.
  * params_out (>= 512 bytes) <- the kernel argument; info[10] <- {its size, grid, block, dynamic LDS bytes, and the template
  * arguments WM, NT, NS, AMODE, EPI, PP of the gemm_bf16_kernel instantiation}.                                              */
 int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info);
+/* ... for a launch on `stream` (the split-K decision depends on the stream's scratch registration) */
+int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* stream, void* params_out, int32_t* info);
 
 /* ------------------------------------------------------------------------ */
 /* Attention                                                                 */

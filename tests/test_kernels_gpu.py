@@ -286,7 +286,8 @@ def _splits(ops, desc):
     import ctypes as C
     from hi3d_hip import lib as L
     buf, info = C.create_string_buffer(512), (C.c_int32 * 10)()
-    L.check(L.load().hi3d_debug_gemm_launch_info(C.byref(desc), buf, info), "hi3d_debug_gemm_launch_info")
+    L.check(L.load().hi3d_debug_gemm_launch_info_on(C.byref(desc), torch.cuda.current_stream().cuda_stream, buf, info),
+            "hi3d_debug_gemm_launch_info_on")
     grid, WM, NT = info[1], info[4], info[5]
     tiles = -(-desc.M // (64 * WM)) * -(-desc.N // (32 * NT))
     assert grid % tiles == 0
@@ -347,15 +348,66 @@ def test_gemm_split_k(dev, kind):
     out32 = ops.gemm(Ad, Wd, M=M, N=N, K=K, bias=bias.to(dev), out_fp32=True, **kw)
     assert relerr(out32, acc + bias) < 2e-5
     lib = L.load()
-    ws = ops._GEMM_WS[dev.index or 0]
+    st = torch.cuda.current_stream().cuda_stream
+    ws = ops._GEMM_WS[(dev.index or 0, st)]
     try:
-        L.check(lib.hi3d_gemm_set_workspace(None, 0), "hi3d_gemm_set_workspace")
+        L.check(lib.hi3d_gemm_set_workspace_for_stream(None, 0, st), "hi3d_gemm_set_workspace_for_stream")     # withdrawn
         assert _splits(ops, ops.gemm_desc(Ad, Wd, **args)[0]) == 1
         plain = ops.gemm(Ad, Wd, **args)
     finally:
-        L.check(lib.hi3d_gemm_set_workspace(C.c_void_p(ws.data_ptr()), ws.numel()), "hi3d_gemm_set_workspace")
+        L.check(lib.hi3d_gemm_set_workspace_for_stream(C.c_void_p(ws.data_ptr()), ws.numel(), st), "hi3d_gemm_set_workspace_for_stream")
     assert relerr(plain, ref) < BF16_TOL
     assert relerr(out, plain.float().cpu()) < 8e-3                      # same math, different fp32 summation order + one bf16 rounding
+
+
+def test_gemm_split_k_scratch_is_per_stream(dev):
+    """the split-K scratch used to be ONE buffer per device, shared silently by every stream -- two split-K GEMMs in
+    flight on two streams wrote the same fp32 partial tiles.  Now a buffer belongs to a stream: each stream that runs GEMMs
+    through hi3d_hip.ops gets its own (hi3d_gemm_set_workspace_for_stream), a stream without one does not split, and the
+    stream-less registration is claimed by the first stream that uses it.  Two streams hammering split-K launches with
+    different operands concurrently must each reproduce their single-stream result bit for bit."""
+    import ctypes as C
+    from hi3d_hip import lib as L
+    from hi3d_hip import ops
+    lib = L.load()
+    M, N, K = 2048, 1280, 5120                    # 16 x 8 tiles of 128 x 160: split 4-fold
+    def case(seed):
+        A, W = bf(rnd((M, K), seed)).to(dev), bf(rnd((N, K), seed + 1, K ** -0.5)).to(dev)
+        return A, W, rnd((N,), seed + 2).to(dev)
+    cases = [case(100), case(200)]
+    refs = []
+    for A, W, b in cases:                          # single-stream results (current stream: its own scratch)
+        refs.append(ops.gemm(A, W, M=M, N=N, K=K, bias=b))
+        d, _ = ops.gemm_desc(A, W, M=M, N=N, K=K, bias=b)
+        assert _splits(ops, d) >= 2
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(30):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                A, W, b = cases[i]
+                outs[i].append(ops.gemm(A, W, M=M, N=N, K=K, bias=b))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert all(torch.equal(o, refs[i]) for o in outs[i]), f"stream {i}: a concurrent split-K launch corrupted the partial tiles"
+    assert len({k for k in ops._GEMM_WS if k[0] == (dev.index or 0)}) >= 3          # one scratch per stream that ran GEMMs
+    # the stream-less registration: claimed by the first stream, refused to the second
+    s3, s4 = torch.cuda.Stream(), torch.cuda.Stream()
+    buf = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
+    L.check(lib.hi3d_gemm_set_workspace(C.c_void_p(buf.data_ptr()), buf.numel()), "hi3d_gemm_set_workspace")
+    try:
+        A, W, b = cases[0]
+        d, out = ops.gemm_desc(A, W, M=M, N=N, K=K, bias=b)
+        L.check(lib.hi3d_gemm_bf16(d, s3.cuda_stream), "hi3d_gemm_bf16")            # claims it: splits
+        s3.synchronize()
+        assert torch.equal(out, refs[0])
+        d2, out2 = ops.gemm_desc(A, W, M=M, N=N, K=K, bias=b)
+        L.check(lib.hi3d_gemm_bf16(d2, s4.cuda_stream), "hi3d_gemm_bf16")           # another stream: no scratch -> does not split
+        s4.synchronize()
+        assert relerr(out2, refs[0].float().cpu()) < 8e-3 and not torch.equal(out2, refs[0])
+    finally:
+        L.check(lib.hi3d_gemm_set_workspace(None, 0), "hi3d_gemm_set_workspace")
 
 
 @pytest.mark.parametrize("inst,P,C1,C2,silu", [(3, 100, 64, 64, True), (2, 777, 320, 640, True), (2, 64, 1280, 1280, False),

@@ -17,7 +17,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("HI3D_GEMM_SPLITK", "0")     # the split-K scratch is one buffer per device: not for two concurrent streams
+# (round 4: the split-K scratch is per stream -- hi3d_gemm_set_workspace_for_stream -- so the two streams may both split)
 sys.path.insert(0, os.path.join(ROOT, "hi3d-official_amd"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
