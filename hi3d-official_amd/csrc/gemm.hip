@@ -529,6 +529,44 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     char* const slab = smem + w * WSLAB;
     const int wcol0 = n0_out + wn * WOUT;                                // first output column of this wave
     const long wrow0 = (long)m0 + wm * 64;                               // first row of this wave
+    // ---- GroupNorm statistics of this wave's 64 x 16*NT output block, from the accumulators (GemmParams.gn_part).  A lane's
+    // 4*NT consecutive columns start at a multiple of 4*NT and so cover WHOLE groups of N/32 channels at every width the host
+    // admits (4*NT = 40: 10 / 20 / 40 channels per group = 320 / 640 / 1280 wide; 4*NT = 32: 8 / 16 / 32): per lane NG
+    // (sum, sum of squares) pairs over its 4 x 4*NT values, a 4-step butterfly over the 16 lanes that hold the other rows,
+    // one 8*NG-byte store per (64-row block, column quarter).  Every (block, group) pair is written by exactly one lane of the
+    // grid: plain stores, fixed summation order, bitwise reproducible.  The accumulators already carry bias + row vector.
+    if (EPI == HI3D_EPI_AFFINE && p.gn_part) {
+      constexpr int LC = 4 * NT;
+      auto gn_block = [&](auto ng_) {
+        constexpr int NG = decltype(ng_)::value, CPG = LC / NG;
+        float s[NG], q[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { s[j] = 0.f; q[j] = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[mt][nt][r];
+              s[(nt * 4 + r) / CPG] += v;
+              q[(nt * 4 + r) / CPG] += v * v;
+            }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+          for (int j = 0; j < NG; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+        if (fr == 0) {
+          float* dst = p.gn_part + (wrow0 >> 6) * 64 + ((n0 + wn * 16 * NT + fg * LC) / CPG) * 2;
+#pragma unroll
+          for (int j = 0; j < NG; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = q[j]; }
+        }
+      };
+      const int cpg = p.N >> 5;
+      if (cpg * 4 == LC) gn_block(std::integral_constant<int, 4>{});
+      else if (cpg * 2 == LC) gn_block(std::integral_constant<int, 2>{});
+      else gn_block(std::integral_constant<int, 1>{});
+    }
     const __amdgpu_buffer_rsrc_t rsOw =
         __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
     // chunk i of a pass = lane + 64 i: slab row / column, the same in all four passes -- its LDS, bias, output and
@@ -783,6 +821,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 // packed kernel argument -- written here instead of launched.  Used by hi3d_hip/devtools/isa_stress.py, which re-assembles
 // the kernel's device code with timing perturbations and launches it through the HIP module API.
 struct GemmCapture { GemmParams p; int grid, block, smem, WM, NT, NS, AMODE, EPI, PP; };
+thread_local int g_gn_fused = 0;     // set by hi3d_gemm_bf16: the launch it made (or described) fills GemmParams.gn_part
 thread_local GemmCapture* g_capture = nullptr;
 
 template <int WM, int NT, int NS, int AMODE, int EPI, bool PP = false>
@@ -926,6 +965,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW; p.pad = d->pad_br_only ? 0 : 1;
   p.A2 = (const char*)d->A2; p.lda2 = d->lda2; p.K1 = d->K1;
+  p.gn_part = nullptr; g_gn_fused = 0;
   const bool two = d->A2 != nullptr;
   if (two) {
     if (d->amode != HI3D_A_DENSE || d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: A2 (two-source A) needs dense A and the affine epilogue");
@@ -1057,6 +1097,15 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     HI3D_LAUNCH_CHECK();
     return HI3D_OK;
   }
+  // GroupNorm statistics of the output from the producer's accumulators (GemmParams.gn_part): the wide ping-pong tile, full
+  // tiles only, nothing added after the accumulators (no residual / blend; a row vector only when it is per tile), and a
+  // channel count whose groups are whole inside a lane's 4*NT columns
+  if (d->gn_partial && (variant == 7 || variant == 8) && d->epi == HI3D_EPI_AFFINE && !d->R1 && !d->R2 && !d->a1 && !d->a2 &&
+      !d->out_fp32 && d->M % 256 == 0 && d->N % tile == 0 && d->N % 32 == 0 && (!d->rowvec || d->rows_per_group % 256 == 0) &&
+      ((uintptr_t)d->gn_partial & 7) == 0 && !getenv("HI3D_GN_FUSED_OFF")) {
+    const int lc = tile == 320 ? 40 : 32, cpg = d->N / 32;
+    if (cpg == lc || cpg * 2 == lc || cpg * 4 == lc) { p.gn_part = d->gn_partial; g_gn_fused = 1; }
+  }
   if (tile == 256) return dispatch<4, 8, 2, true>(p, amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, amode, d->epi, s) : dispatch<4, 10, 2>(p, amode, d->epi, s);
   if (tile == 32) {
@@ -1115,4 +1164,15 @@ extern "C" int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* str
 
 extern "C" int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info) {
   return hi3d_debug_gemm_launch_info_on(d, nullptr, params_out, info);
+}
+
+// 1 when hi3d_gemm_bf16(d, stream) fills d->gn_partial (the consumer may then call hi3d_groupnorm_silu_from_partials), 0 when
+// the launch it would make cannot (tile variant, tails, residual terms ...: the consumer runs the full hi3d_groupnorm_silu),
+// negative on an invalid descriptor.  Nothing is launched.
+extern "C" int hi3d_gemm_gn_partial_supported(const hi3d_gemm_desc* d, void* stream) {
+  GemmCapture c;
+  g_capture = &c;
+  const int rc = hi3d_gemm_bf16(d, stream);
+  g_capture = nullptr;
+  return rc ? rc : g_gn_fused;
 }

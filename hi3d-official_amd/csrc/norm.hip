@@ -387,6 +387,32 @@ extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, c
   return groupnorm_launch(x, nullptr, C, y, gamma, beta, ws, inst, P, C, eps, apply_silu, stream);
 }
 
+extern "C" int hi3d_groupnorm_silu_from_partials(const void* x, void* y, const float* gamma, const float* beta,
+                                                 float* ws, int32_t inst, int32_t P, int32_t C, float eps,
+                                                 int32_t apply_silu, void* stream) {
+  if (!x || !y || !gamma || !beta || !ws) HI3D_FAIL(HI3D_EINVAL, "groupnorm: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (P % 64) HI3D_FAIL(HI3D_ESHAPE, "groupnorm_from_partials: P must be a multiple of the 64-row partial blocks");
+  if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = P / 64;                               // == hi3d_gn_partial_blocks(P, C): the stats slot sits right behind
+  float* stats = ws + (long)inst * nblk * 64;
+  const double inv_count = 1.0 / ((double)P * (double)(C / 32));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, ws, stats, nblk, inv_count, eps);
+  HI3D_LAUNCH_CHECK();
+  const int ppb = gn_ppb(inst, P);
+  const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
+  const int ablk = (P + appb - 1) / appb;
+  const int nthr = gn_threads(C);
+  if (apply_silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)nullptr, 0, (uint4*)y, gamma, beta, stats, P, C, appb);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ablk, inst), dim3(nthr), 0, s, (const uint4*)x, (const uint4*)nullptr, 0, (uint4*)y, gamma, beta, stats, P, C, appb);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
 extern "C" int hi3d_groupnorm_silu_cat2(const void* x1, const void* x2, void* y, const float* gamma, const float* beta,
                                         float* ws, int32_t inst, int32_t P, int32_t C1, int32_t C2, float eps,
                                         int32_t apply_silu, void* stream) {

@@ -139,16 +139,25 @@ def _ensure_gemm_workspace(dev, stream=None):
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, gn=None):
     """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
     A2 / K1: two-source dense A -- logical A = [A[:, :K1] | A2[:, :K - K1]] (the decoder's skip concat, never materialised).
-    """
+    gn = (inst, P): the output is the input of a GroupNorm(32) over `inst` instances of P rows -- ask the producer to emit the
+    norm's partial sums from its accumulators (hi3d_gemm_desc.gn_partial).  Returns (out, ws): ws is the GroupNorm workspace
+    holding them (pass it to groupnorm_silu(..., partials=ws): the statistics pass is skipped), or None when this launch
+    cannot provide them (the caller then runs the plain groupnorm_silu)."""
     d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
                        a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n,
                        A2=A2, K1=K1, lda2=lda2)
     _ensure_gemm_workspace(A.device)
+    gn_ws = None
+    if gn is not None and GN_FUSED and gn[1] % 64 == 0 and gn[0] * gn[1] == M:
+        gn_ws = _gn_workspace(A.device, gn[0], gn[1], n_out)
+        d.gn_partial = _p(gn_ws)
+        if _lib.hi3d_gemm_gn_partial_supported(d, _stream()) != 1:
+            d.gn_partial, gn_ws = 0, None
     n_out = N // 2 if geglu else N
     prof = PROFILER
     t0 = prof.begin() if prof else None
@@ -170,7 +179,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         osz = 2.0 if out_fp32 else 1.0
         prof.end(fam, 2.0 * M * N * K, 2.0 * (a_elems + N * K + M * n_out * (osz + nres)), t0,
                  detail=f"M={M} N={N} K={K}{geo} {epi}")
-    return out
+    return out if gn is None else (out, gn_ws)
 
 
 def transpose_v(v_view, B, H, S, ldv):
@@ -293,12 +302,26 @@ def attention_temporal_fused_qkv(qkv, B, T, S, H, scale=None):
 
 
 _gn_ws = {}
+# HI3D_GN_FUSED=0: every GroupNorm runs its own statistics pass (rounds 1-3; A/B switch)
+GN_FUSED = os.environ.get("HI3D_GN_FUSED", "1") != "0"
 
 
-def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None, x2=None):
+def _gn_workspace(dev, inst, P, C):
+    """the per-(device, stream) GroupNorm scratch (partial sums + per-instance statistics), grown on demand"""
+    n = _lib.hi3d_gn_workspace_floats(inst, P, C)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 16), device=dev, dtype=torch.float32)
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None, x2=None, partials=None):
     """x: bf16 [inst*P, C] contiguous. 32 groups, statistics over (P, C/32).
     x2: second source -- the normalised tensor is the channel concatenation [x | x2] (C = C1 + C2 total channels, x holds
     C1 = x.shape[-1] of them), read in place; the result is the full-width [inst*P, C] tensor.
+    partials: the workspace a producing gemm(..., gn=(inst, P)) filled with this tensor's partial sums: finalize + apply only.
     (Tried, MI355X: processing runs of instances that fit the 256 MB Infinity Cache so that the second read of x
     hits it -- 0.204 -> 0.236-0.248 ms at [32 x 16384 x 320]: the smaller grids cost more than the re-read.)"""
     _chk_dev(x, gamma, beta, out, x2)
@@ -311,19 +334,18 @@ def groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu=True, out=None, x2=None
         assert x.is_contiguous() and x2.is_contiguous() and x.numel() == inst * P * C1 and x2.numel() == inst * P * (C - C1)
         if out is None:
             out = torch.empty((inst * P, C), device=x.device, dtype=torch.bfloat16)
-    return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2)
+    return _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2, partials)
 
 
-def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2=None):
-    n = _lib.hi3d_gn_workspace_floats(inst, P, C)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(max(n, 1 << 16), device=x.device, dtype=torch.float32)
-        _gn_ws[key] = ws
+def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2=None, partials=None):
+    ws = _gn_workspace(x.device, inst, P, C) if partials is None else partials
     prof = PROFILER
     t0 = prof.begin() if prof else None
-    if x2 is None:
+    if partials is not None:
+        assert x2 is None
+        _l.check(_lib.hi3d_groupnorm_silu_from_partials(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
+                                                        float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu_from_partials")
+    elif x2 is None:
         _l.check(_lib.hi3d_groupnorm_silu(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C,
                                           float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu")
     else:

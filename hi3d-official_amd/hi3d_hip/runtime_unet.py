@@ -281,9 +281,10 @@ class UNetRuntime:
         geo = dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0)
         eo, _ = self.emb_slices[p]
         h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5, x2=x2)
-        h = ops.gemm(h, W[p + ".in_layers.2.w"], M=M, N=Cout, K=9 * Cin, bias=W[p + ".in_layers.2.b"],
-                     rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, conv3x3=geo)
-        h = ops.groupnorm_silu(h, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.b"], F_, HW, Cout, 1e-5)
+        # (the conv also emits the partial sums of the GroupNorm that reads its output: no statistics pass over h)
+        h, gp = ops.gemm(h, W[p + ".in_layers.2.w"], M=M, N=Cout, K=9 * Cin, bias=W[p + ".in_layers.2.b"],
+                         rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, conv3x3=geo, gn=(F_, HW))
+        h = ops.groupnorm_silu(h, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.b"], F_, HW, Cout, 1e-5, partials=gp)
         if x2 is not None:     # (Cin = C1 + C2 != Cout: the reference builds a skip_connection conv for every decoder ResBlock)
             C1 = x.numel() // M
             skip = ops.gemm(x, W[p + ".skip.w"], M=M, N=Cout, K=Cin, bias=W[p + ".skip.b"], A2=x2, K1=C1)
@@ -297,18 +298,21 @@ class UNetRuntime:
         eo, _ = self.emb_slices[q]
         if sp is None:
             HWt, emb_t = HW, emb_all
-            gn3 = lambda t, k: ops.groupnorm_silu(t, W[k + ".g"], W[k + ".b"], B, T * HW, Cout, 1e-5)
+            gn3 = lambda t, k, gp=None: ops.groupnorm_silu(t, W[k + ".g"], W[k + ".b"], B, T * HW, Cout, 1e-5, partials=gp)
         else:                                   # rows (b t s_local): every frame, this GPU's pixels
             HWt, emb_t = HW // sp.world, emb_full
             xs = sp.frames_to_space(xs, B, HW)
-            gn3 = lambda t, k: ops.groupnorm_silu_sharded(t, W[k + ".g"], W[k + ".b"], B, T * HWt, Cout, 1e-5,
-                                                          sp.allreduce_sum_, sp.world)
+            gn3 = lambda t, k, gp=None: ops.groupnorm_silu_sharded(t, W[k + ".g"], W[k + ".b"], B, T * HWt, Cout, 1e-5,
+                                                                   sp.allreduce_sum_, sp.world)
         Mt = B * T * HWt
         tg = dict(T=T, HW=HWt, Cin=Cout)
         h = gn3(xs, q + ".in_layers.0")
-        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
-                     rowvec=emb_t[:, eo:], ldrv=self.emb_total, rows_per_group=HWt, convt3=tg)
-        h = gn3(h, q + ".out_layers.0")
+        # (single GPU: the Conv3d emits the partial sums of the 3-D GroupNorm that follows; a space-sharded clip needs this
+        # GPU's sums for the all-reduce and keeps the separate pass -- gn = (0, 0) never qualifies)
+        h, gp = ops.gemm(h, W[q + ".in_layers.2.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
+                         rowvec=emb_t[:, eo:], ldrv=self.emb_total, rows_per_group=HWt, convt3=tg,
+                         gn=(B, T * HWt) if sp is None else (0, 0))
+        h = gn3(h, q + ".out_layers.0", gp)
         # alpha*x_s + (1-alpha)*(x_s + h_t)  ==  x_s + (1-alpha)*h_t     (video_model.py:77-79)
         out = ops.gemm(h, W[q + ".out_layers.3.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
                        a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HWt, convt3=tg)

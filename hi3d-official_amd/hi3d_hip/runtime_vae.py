@@ -89,16 +89,16 @@ class VAEDecoderRuntime:
         self.W = W
 
     # ------------------------------------------------------------------
-    def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False):
+    def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False, gn=None):
         Ho, Wo = (2 * H, 2 * Wd) if up else (H, Wd)
         return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
-                        out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up))
+                        out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up), gn=gn)
 
     def _resnet(self, p, x, N, H, Wd, Cin, Cout):
         W, HW = self.W, H * Wd
         h = ops.groupnorm_silu(x, W[p + ".norm1.g"], W[p + ".norm1.b"], N, HW, Cin, 1e-6)
-        h = self._conv(h, p + ".conv1", N, H, Wd, Cin, Cout)
-        h = ops.groupnorm_silu(h, W[p + ".norm2.g"], W[p + ".norm2.b"], N, HW, Cout, 1e-6)
+        h, gp = self._conv(h, p + ".conv1", N, H, Wd, Cin, Cout, gn=(N, HW))      # (+ norm2's partial sums where the tile allows)
+        h = ops.groupnorm_silu(h, W[p + ".norm2.g"], W[p + ".norm2.b"], N, HW, Cout, 1e-6, partials=gp)
         skip = x
         if (p + ".nin.w") in W:
             skip = ops.gemm(x, W[p + ".nin.w"], M=N * HW, N=Cout, K=Cin, bias=W[p + ".nin.b"])

@@ -108,6 +108,13 @@ typedef struct hi3d_gemm_desc {
    * written.  HI3D_A_DENSE + HI3D_EPI_AFFINE only; K1 % 64 == 0. */
   const void* A2;
   int32_t K1, lda2;
+  /* GroupNorm statistics of the OUTPUT from the producer (round 4; NULL = off): when the launch qualifies
+   * (hi3d_gemm_gn_partial_supported: wide tile, M % 256 == 0, N a whole number of tiles, no R1 / R2 / a1 / a2, bf16 out) the
+   * kernel also writes, per 64-row block b of the output and per group g of N / 32 channels, the (sum, sum of squares) of the
+   * fp32 results to gn_partial[b * 64 + 2 g + {0, 1}] -- M / 64 * 64 floats, the partial-sum layout of hi3d_groupnorm_silu's
+   * workspace with 64-pixel blocks -- so the GroupNorm that follows (openaimodel.py:292-294 `out_layers` after the
+   * `in_layers` conv; the time_stack likewise) reads the tensor once (hi3d_groupnorm_silu_from_partials). */
+  float* gn_partial;
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
@@ -130,6 +137,8 @@ int hi3d_gemm_set_workspace_for_stream(void* ptr, int64_t bytes, void* stream);
 int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32_t* info);
 /* ... for a launch on `stream` (the split-K decision depends on the stream's scratch registration) */
 int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* stream, void* params_out, int32_t* info);
+/* 1 if hi3d_gemm_bf16(d, stream) will fill d->gn_partial, 0 if that launch cannot (nothing is launched) */
+int hi3d_gemm_gn_partial_supported(const hi3d_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Attention                                                                 */
@@ -221,6 +230,11 @@ int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float*
  * decoder's `h = th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) followed by the ResBlock's in_layers GroupNorm
  * (openaimodel.py:257-259) without the concatenated tensor ever being written (round 4).  C1, C2 multiples of 8,
  * (C1 + C2) % 32 == 0; ws as hi3d_gn_workspace_floats(inst, P, C1 + C2).                                        */
+/* hi3d_groupnorm_silu without its statistics pass: ws already holds the partial sums [inst][P / 64][32][2] written by the
+ * producing GEMM (hi3d_gemm_desc.gn_partial = ws); P % 64 == 0.  finalize + apply only: x is read once. */
+int hi3d_groupnorm_silu_from_partials(const void* x, void* y, const float* gamma, const float* beta,
+                                      float* ws, int32_t inst, int32_t P, int32_t C,
+                                      float eps, int32_t apply_silu, void* stream);
 int hi3d_groupnorm_silu_cat2(const void* x1, const void* x2, void* y, const float* gamma, const float* beta,
                              float* ws, int32_t inst, int32_t P, int32_t C1, int32_t C2,
                              float eps, int32_t apply_silu, void* stream);

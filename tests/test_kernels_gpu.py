@@ -429,6 +429,43 @@ def test_groupnorm_cat2(dev, inst, P, C1, C2, silu):
     assert relerr(c, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("variant,N,three_d", [(7, 320, False), (7, 640, True), (7, 1280, False), (8, 256, False), (8, 512, True)])
+def test_groupnorm_statistics_from_the_producing_conv(dev, variant, N, three_d, monkeypatch):
+    """Round 4: a conv whose output feeds a GroupNorm (ResBlock in_layers.2 -> out_layers.0, openaimodel.py:292-305; the
+    time_stack likewise) emits that norm's partial sums from its accumulators (hi3d_gemm_desc.gn_partial, wide ping-pong tile),
+    and the norm runs finalize + apply only (hi3d_groupnorm_silu_from_partials): x is read once instead of twice.  Against
+    the plain three-pass norm of the same tensor (the sums are taken over the fp32 results before their bf16 rounding, so the
+    two agree to rounding noise, not bit for bit) and against F.group_norm; 2-D (instance = frame) and 3-D (instance = clip)
+    instance shapes; every group width a lane's columns can hold; launches that cannot provide the sums say so."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
+    Fr, H, Cin = 6, 32, 64
+    M, HW = Fr * H * H, H * H                                 # 6144 rows = 24 tiles of 256
+    x = bf(rnd((Fr, Cin, H, H), 1))
+    w, bias = bf(rnd((N, Cin, 3, 3), 2, (9 * Cin) ** -0.5)).float(), rnd((N,), 3)
+    rv = rnd((Fr, N), 4)
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin).to(dev)
+    geo = dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up2x=0)
+    inst, P = (2, 3 * HW) if three_d else (Fr, HW)
+    kw = dict(M=M, N=N, K=9 * Cin, bias=bias.to(dev), rowvec=rv.to(dev), ldrv=N, rows_per_group=HW, conv3x3=geo)
+    out, gp = ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), **kw)
+    assert gp is not None, "this launch was expected to emit the GroupNorm partial sums"
+    plain_out = ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), **kw)
+    assert torch.equal(out, plain_out)                        # the statistics do not touch the product
+    g, b = rnd((N,), 5).abs() + 0.5, rnd((N,), 6)
+    fused = ops.groupnorm_silu(out, g.to(dev), b.to(dev), inst, P, N, 1e-5, partials=gp)
+    three_pass = ops.groupnorm_silu(out, g.to(dev), b.to(dev), inst, P, N, 1e-5)
+    ref = F.silu(F.group_norm(out.float().cpu().reshape(inst, P, N).permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1).reshape(M, N)
+    assert relerr(fused, ref) < BF16_TOL
+    assert relerr(fused, three_pass.float().cpu()) < 8e-3
+    # launches that cannot provide the sums: a residual epilogue, a ragged M, a narrow tile
+    R1 = bf(rnd((M, N), 7)).to(dev)
+    assert ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), R1=R1, **kw)[1] is None
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", "0")
+    assert ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), **kw)[1] is None
+
+
 @pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 2, 16), (1, 1, 4), (1, 3, 129)])
 def test_attention_d64(dev, B, H, S):
     from hi3d_hip import ops
