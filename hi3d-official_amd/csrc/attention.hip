@@ -284,24 +284,48 @@ __global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
 
     // O^T += V^T P^T   (k-step ks covers keys ks*16 .. ks*16+15 of the tile); every V^T
     // fragment feeds QB MFMAs.  Keys >= S_kv: P = 0 and the V^T columns are the zero padding.
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 vf;
-        if (VROW) {
+    if (VROW) {
 #if __HIP_DEVICE_COMPILE__
-          const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(v_tr + db * 4096 + ks * 1024));
-          const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(v_tr + db * 4096 + ks * 1024 + 256));
-          vf = bf16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#endif
-        } else {
-          vf = *(const bf16x8*)(v_ptr[ks] + db * 32 * 128);
-        }
+      // The 16 transposing reads of the tile in inline assembly: the compiler's waitcnt pass puts `s_waitcnt vmcnt(0)` in front
+      // of the first ds_read_b64_tr_b16 it sees while LDS-DMA is in flight (the builtin is not disambiguated against the DMA
+      // target the way plain ds_read is) -- a wait for the NEXT tile's K / V requests in the middle of this tile.  All 16 are
+      // issued, the first product block starts when its 8 have returned (LDS returns in order: lgkmcnt(8)), the second at 0;
+      // the waits carry the registers as operands so that the MFMAs cannot be scheduled above them.
+      bf16x4 vt[2][4][2];
+      const unsigned va = (unsigned)(__UINTPTR_TYPE__)(LDS_AS char*)v_tr;
+#define HI3D_TR(DB, KS, H) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[DB][KS][H]) : "v"(va), "n"((DB) * 4096 + (KS) * 1024 + (H) * 256))
+      HI3D_TR(0, 0, 0); HI3D_TR(0, 0, 1); HI3D_TR(0, 1, 0); HI3D_TR(0, 1, 1); HI3D_TR(0, 2, 0); HI3D_TR(0, 2, 1); HI3D_TR(0, 3, 0); HI3D_TR(0, 3, 1);
+      HI3D_TR(1, 0, 0); HI3D_TR(1, 0, 1); HI3D_TR(1, 1, 0); HI3D_TR(1, 1, 1); HI3D_TR(1, 2, 0); HI3D_TR(1, 2, 1); HI3D_TR(1, 3, 0); HI3D_TR(1, 3, 1);
+#undef HI3D_TR
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-          o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], o[qb][db], 0, 0, 0);
+      for (int db = 0; db < 2; ++db) {
+        if (db == 0)
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                                                "+v"(vt[0][2][0]), "+v"(vt[0][2][1]), "+v"(vt[0][3][0]), "+v"(vt[0][3][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),
+                                                "+v"(vt[1][2][0]), "+v"(vt[1][2][1]), "+v"(vt[1][3][0]), "+v"(vt[1][3][1]));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x4 v0 = vt[db][ks][0], v1 = vt[db][ks][1];
+          const bf16x8 vf = bf16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], o[qb][db], 0, 0, 0);
+        }
       }
+#endif
+    } else {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 vf = *(const bf16x8*)(v_ptr[ks] + db * 32 * 128);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], o[qb][db], 0, 0, 0);
+        }
+    }
     // flip the fragment pointers to the other ring stage
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { k_ptr[ks] += stage_step; v_ptr[ks] += stage_step; }

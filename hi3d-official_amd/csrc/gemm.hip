@@ -552,10 +552,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
               s[(nt * 4 + r) / CPG] += v;
               q[(nt * 4 + r) / CPG] += v * v;
             }
+        // sum over the 16 lanes of this lane's row group (fr): rotate-and-add inside the DPP row -- v_add_f32 with a row_ror
+        // modifier, no LDS round trip (__shfl_xor lowers to ds_bpermute: 32 of them per tile cost more than the pass they save)
+        auto row_sum = [](float v) {
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+          return v;
+        };
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1)
-#pragma unroll
-          for (int j = 0; j < NG; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+        for (int j = 0; j < NG; ++j) { s[j] = row_sum(s[j]); q[j] = row_sum(q[j]); }
         if (fr == 0) {
           float* dst = p.gn_part + (wrow0 >> 6) * 64 + ((n0 + wn * 16 * NT + fg * LC) / CPG) * 2;
 #pragma unroll

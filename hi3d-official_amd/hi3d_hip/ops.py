@@ -152,6 +152,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
                        a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n,
                        A2=A2, K1=K1, lda2=lda2)
     _ensure_gemm_workspace(A.device)
+    n_out = N // 2 if geglu else N
     gn_ws = None
     if gn is not None and GN_FUSED and gn[1] % 64 == 0 and gn[0] * gn[1] == M:
         gn_ws = _gn_workspace(A.device, gn[0], gn[1], n_out)
@@ -219,6 +220,24 @@ def attention_d64_v(q, k, v, B, H, S_q, S_kv, ldq, ldk, ldv, scale, out=None):
              "hi3d_attn_d64_v")
     if prof:
         prof.end("attn_d64", 4.0 * B * H * S_q * S_kv * 64, 2.0 * B * H * 64 * (2 * S_q + 2 * S_kv), t0)
+    return out
+
+
+def attention_d512(qkv, B, S, scale=None, out=None):
+    """Single-head attention of head dim 512 on a fused [B*S, 3*512] q | k | v projection (the VAE mid block): flash-style,
+    no score matrix in memory.  Returns [B*S, 512]."""
+    _chk_dev(qkv, out)
+    assert qkv.shape == (B * S, 3 * 512) and qkv.stride(1) == 1
+    if out is None:
+        out = torch.empty((B * S, 512), device=qkv.device, dtype=torch.bfloat16)
+    scale = 512 ** -0.5 if scale is None else scale
+    ld = qkv.stride(0)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_attn_d512(_p(qkv), _p(qkv[:, 512:]), _p(qkv[:, 1024:]), _p(out), B, S, ld, ld, ld, out.stride(0),
+                                 float(scale), _stream()), "hi3d_attn_d512")
+    if prof:
+        prof.end("attn_d512", 4.0 * B * S * S * 512, 2.0 * B * S * 512 * 4, t0)
     return out
 
 

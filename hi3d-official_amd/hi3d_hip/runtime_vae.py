@@ -15,6 +15,8 @@ across GPUs, all-gather of the decoded frames afterwards).
 """
 import functools
 
+import os
+
 import torch
 
 from . import ops, pack
@@ -33,6 +35,13 @@ def _on_own_device(fn):
         with torch.cuda.device(dev):
             return fn(self, *args, **kwargs)
     return wrapped
+
+
+# HI3D_VAE_FLASH=1: the mid-block attention as ONE flash-style launch (hi3d_attn_d512: no score matrix in memory).  Measured
+# on a 1024 x 1024 frame (16384 tokens, profiles/r04j_vae_flash_ab.log): 1.14 ms against 1.02 ms for GEMM -> fp32 scores (1 GiB)
+# -> softmax -> GEMM, whose two products run on the tuned wide GEMM tile -- so the three-launch form stays the default where
+# the score buffer fits, and the flash kernel is the opt-in for memory-constrained use (and SURVEY 8b's `attn_fwd_d512`).
+VAE_FLASH = os.environ.get("HI3D_VAE_FLASH", "0") == "1"
 
 
 class VAEDecoderRuntime:
@@ -110,6 +119,10 @@ class VAEDecoderRuntime:
             raise ops._l.Hi3dError("attention width must be a multiple of 64")
         n = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], N, S, C, 1e-6, silu=False)
         qkv = ops.gemm(n, W[p + ".qkv.w"], M=N * S, N=3 * C, K=C, bias=W[p + ".qkv.b"])
+        if C == 512 and VAE_FLASH:
+            # round 4: one flash-style launch (hi3d_attn_d512), no score matrix in memory
+            o = ops.attention_d512(qkv, N, S)
+            return ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x)
         vt = ops.transpose_v(qkv[:, 2 * C:], N, C // 64, S, 3 * C)          # [N, C/64, 64, S_pad] == V^T [N][C][S_pad]
         S_pad = vt.shape[-1]
         o = torch.empty((N * S, C), device=x.device, dtype=torch.bfloat16)

@@ -193,6 +193,14 @@ int64_t hi3d_attn_fp8_v_workspace_bytes(int32_t B, int32_t H, int32_t S);
 int hi3d_attn_quant_v(const void* v, void* ws_v, int32_t B, int32_t H, int32_t S, int32_t ldv, void* stream);
 int hi3d_attn_d64_fp8(const void* ws, const void* ws_v, void* out, int32_t B, int32_t H, int32_t S, int32_t ldo, void* stream);
 
+/* Single-head flash attention, head dim 512, bf16 in / out, fp32 accumulate and softmax: the mid-block attention of the VAE
+ * encoder / decoder (sgm/modules/diffusionmodules/model.py:180-195 AttnBlock, 226-257 MemoryEfficientAttnBlock: 16384 tokens
+ * per 1024 x 1024 frame).  SURVEY 8b's `attn_fwd_d512`; rounds 1-3 wrote the fp32 score matrix (1 GiB per frame) instead.
+ *   q, k, v : rows of 512 contiguous bf16 at base + (b*S + s)*ld   (e.g. the three column blocks of a fused projection)
+ *   out     : [B][S][ldo];  scale: the softmax scale (512^-0.5 in the reference), applied to the fp32 scores.           */
+int hi3d_attn_d512(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S,
+                   int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
+
 /* vt[b][h][d][s] = v[(b*S+s)*ldv + h*64 + d]  ; S_pad % 64 == 0, pad = 0    */
 int hi3d_transpose_v(const void* v, void* vt, int32_t B, int32_t H, int32_t S,
                      int32_t S_pad, int32_t ldv, void* stream);

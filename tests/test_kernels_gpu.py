@@ -466,6 +466,29 @@ def test_groupnorm_statistics_from_the_producing_conv(dev, variant, N, three_d, 
     assert ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), **kw)[1] is None
 
 
+@pytest.mark.parametrize("B,S", [(2, 256), (1, 1000), (3, 33), (1, 4096), (1, 5)])
+def test_attention_d512(dev, B, S):
+    """hi3d_attn_d512 -- the VAE mid-block attention (one head of 512 channels, model.py:180-195 / 226-257) as ONE flash-style
+    launch, no score matrix in memory -- against fp32 scaled_dot_product_attention on the same bf16 inputs: full tiles, ragged
+    lengths (keys beyond S in the last 32-key tile, query rows beyond S in the last 64-row block), several frames; and a
+    dominant late key (the online rescale of the accumulators)."""
+    from hi3d_hip import ops
+    qkv = bf(rnd((B * S, 3 * 512), 3 + S, 0.6))
+    if S > 40:
+        qkv[S - 7, 512:1024] *= 6.0                      # one key that dominates every query of frame 0: forces the rescale path
+    q, k, v = [t.float().reshape(B, S, 512) for t in qkv.split(512, dim=1)]
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0].reshape(B * S, 512)
+    out = ops.attention_d512(qkv.to(dev), B, S)
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out, ref) < 2e-2                       # P is rounded to bf16 before P V (as in the d64 kernel)
+    # operands inside a wider, NaN-poisoned allocation: rows >= S of the last tile must come back as zeros, not as neighbours
+    big = torch.full((B * S + 96, 3 * 512), float("nan"), dtype=torch.bfloat16)
+    big[:B * S] = qkv
+    bd = big.to(dev)
+    out2 = ops.attention_d512(bd[:B * S], B, S)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("B,H,S", [(2, 2, 256), (1, 5, 100), (2, 1, 1000), (1, 2, 16), (1, 1, 4), (1, 3, 129)])
 def test_attention_d64(dev, B, H, S):
     from hi3d_hip import ops

@@ -73,7 +73,10 @@ def bench_attn(F=32, lat=128):
         vt = ops.transpose_v(qkv[:, 2 * C:], F, H, S, 3 * C)
         out = torch.empty((F * S, C), device=dev, dtype=torch.bfloat16)
         ms = timeit(lambda: ops.attention_d64(qkv, qkv[:, C:], vt, F, H, S, S, 3 * C, 3 * C, 0.125, out=out), iters=5)
-        print(f"  B={F} H={H:2d} S={S:6d}: {ms:8.3f} ms  {4.0 * F * H * S * S * 64 / ms / 1e9:8.1f} TFLOP/s")
+        ms_t = timeit(lambda: ops.transpose_v(qkv[:, 2 * C:], F, H, S, 3 * C), iters=5)
+        ms_v = timeit(lambda: ops.attention_d64_v(qkv, qkv[:, C:], qkv[:, 2 * C:], F, H, S, S, 3 * C, 3 * C, 3 * C, 0.125, out=out), iters=5)
+        print(f"  B={F} H={H:2d} S={S:6d}: V^T operand {ms:8.3f} ms (+ transpose {ms_t:6.3f})  {4.0 * F * H * S * S * 64 / ms / 1e9:8.1f} TFLOP/s | "
+              f"row-major V {ms_v:8.3f} ms  {4.0 * F * H * S * S * 64 / ms_v / 1e9:8.1f} TFLOP/s")
     print("== temporal attention")
     for ds, C in ((1, 320), (2, 640), (4, 1280)):
         S, H = (lat // ds) ** 2, C // 64
