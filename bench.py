@@ -351,6 +351,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         raise SystemExit("non-finite latents after the timed steps")
     steppers = list(unet.runtime(dev).steppers.values())
     graphed = bool(steppers) and steppers[0].graph is not None
+    two_stream = bool(getattr(unet.runtime(dev), "last_forward_two_stream", False))
     # per-kernel breakdown: the same K steps again, launched eagerly with HIP events around every kernel
     prof = ops.Profiler() if profile else None
     if prof is not None:
@@ -378,7 +379,9 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                                f"(CFG batch {2 * T}, latent {lat}x{lat}, in_channels {cfg['in_channels']}), "
                                "EulerEDM 25-step schedule, random-init 1.52B-param UNet",
                    "global_batch": 2 * T * world, "parallelism": f"replicas x{world} (one clip per GPU)",
-                   "step_launch": "one HIP-graph replay per step" if graphed else "eager kernel launches"},
+                   "step_launch": "one HIP-graph replay per step" if graphed else "eager kernel launches",
+                   "streams": "two HIP streams inside the step: the unconditional / conditional halves of the batch through the "
+                              "two largest resolution levels side by side (HI3D_TWO_STREAM=auto)" if two_stream else "one"},
     }
     step_tf = STEP_TFLOP[stage] * (T / 16.0)
     summ = prof.summary() if prof is not None else None
@@ -426,7 +429,11 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                            "launches_per_step": k_n // steps, "avg_launch_ms": round(k_ms / k_n, 4),
                            "share_of_step": round(k_ms / steps / ms_per_step, 3),
                            "timing": f"HIP events around every launch over the {steps} steps after the timed region "
-                                     "(the timed steps are graph replays)"}
+                                     "(the timed steps are graph replays)" +
+                                     ("; in this pass the two CFG halves of the large levels run one after the other on ONE stream "
+                                      "(same kernels and shapes as the timed region, which overlaps them on two streams): per-kernel "
+                                      "durations free of the overlap, their sum exceeds ms_per_step by what the overlap hides"
+                                      if two_stream else "")}
         out["kernels_ms_per_step"] = {f: round(d["ms"] / steps, 3) for f, d in fams}
         for fam in ("attn_d64", "attn_d64_fp8qk", "attn_d64_fp8"):
             if fam not in summ:

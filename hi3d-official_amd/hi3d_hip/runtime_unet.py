@@ -87,6 +87,12 @@ class UNetRuntime:
         self.attn_fp8qk = os.environ.get("HI3D_ATTN_FP8QK", "0") == "1"
         # HI3D_ATTN_FP8=1: both products (Q K^T and P V) on the fp8 matrix path; looser stated tolerance
         self.attn_fp8 = os.environ.get("HI3D_ATTN_FP8", "0") == "1"
+        # HI3D_TWO_STREAM: the two CFG halves of the large levels as two kernel sequences on two streams (forward_tokens).
+        # "auto" (default): when the top level has >= 2^18 token rows (stage 2 at 1024^2: measured -2.0 ms of 204.9 per step;
+        # stage 1 at 512^2 loses 0.4 of 45.1 ms: its half-batch launches under-fill the chip); 1 = always, 0 = never
+        self.two_stream = os.environ.get("HI3D_TWO_STREAM", "auto")
+        self._side, self._plan = None, None
+        self.last_forward_two_stream = False
         self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
         self._pos_cache = {}
         self.steppers = {}      # (T, H, W) -> hi3d_hip.fused_step.FusedStepper
@@ -402,54 +408,177 @@ class UNetRuntime:
         kw = dict(sp=sp, B=B_all)
 
         blocks_in, middle, blocks_out = self.layout
-        h, hs = x_tok, []
-        cur = {"H": H, "W": Wd, "C": CIN_PAD}
+        oc = self.cfg["out_channels"]
+        if oc % 4:
+            raise ops._l.Hi3dError("out_channels must be a multiple of 4")
 
-        def run(h, layers, base, h2=None):
+        class Ctx:                      # what a run of blocks needs to know about the (part of the) batch it works on
+            pass
+
+        def make_ctx(F_c, emb_c, cond_c, a1_c, a_c, kw_c):
+            c = Ctx()
+            c.F, c.emb, c.cond, c.a1, c.a, c.kw = F_c, emb_c, cond_c, a1_c, a_c, kw_c
+            return c
+
+        def run(c, cur, h, layers, base, h2=None):
+            F_c = c.F
             for j, L in enumerate(layers):
                 p = f"{base}.{j}"
                 Hc, Wc = cur["H"], cur["W"]
                 if L[0] == "conv_in":
-                    h = ops.gemm(h, W["conv_in.w"], M=F_ * Hc * Wc, N=mc, K=9 * CIN_PAD, bias=W["conv_in.b"],
+                    h = ops.gemm(h, W["conv_in.w"], M=F_c * Hc * Wc, N=mc, K=9 * CIN_PAD, bias=W["conv_in.b"],
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
                     cur["C"] = mc
                 elif L[0] == "res":
-                    h = self._res(p, h, L[1], L[2], F_, Hc, Wc, T, emb_all, a1_all, emb_full=emb_full, x2=h2, **kw)
+                    h = self._res(p, h, L[1], L[2], F_c, Hc, Wc, T, c.emb, c.a1, emb_full=emb_full, x2=h2, **c.kw)
                     h2 = None
                     cur["C"] = L[2]
                 elif L[0] == "attn":
-                    h = self._transformer(p, h, L[1], F_, Hc * Wc, T, cond, a1_all, a_all, **kw)
+                    h = self._transformer(p, h, L[1], F_c, Hc * Wc, T, c.cond, c.a1, c.a, **c.kw)
                 elif L[0] == "down":
                     Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
-                    h = ops.gemm(h, W[p + ".w"], M=F_ * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"],
+                    h = ops.gemm(h, W[p + ".w"], M=F_c * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"],
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=Ho, Wout=Wo, stride=2, up2x=0))
                     cur["H"], cur["W"] = Ho, Wo
                 elif L[0] == "up":
-                    h = ops.gemm(h, W[p + ".w"], M=F_ * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
+                    h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
                     cur["H"], cur["W"] = 2 * Hc, 2 * Wc
             return h
 
-        for i, layers in enumerate(blocks_in):
-            h = run(h, layers, f"input_blocks.{i}")
-            hs.append((h, cur["C"]))
-        h = run(h, middle, "middle_block")
-        for i, layers in enumerate(blocks_out):
-            s, sc = hs.pop()
+        def run_out_block(c, cur, h, i, layers, s, sc):
             fuse = self.cat_fused and layers[0][0] == "res" and cur["C"] % 64 == 0 and sc % 8 == 0 and \
                 (f"output_blocks.{i}.0.skip.w") in W
             if fuse:           # th.cat (video_model.py:491) as a second source of the ResBlock's two readers
-                h = run(h, layers, f"output_blocks.{i}", h2=s)
-            else:
-                h = ops.concat_channels(h, s, F_ * cur["H"] * cur["W"], cur["C"], sc)
-                h = run(h, layers, f"output_blocks.{i}")
-        Hc, Wc = cur["H"], cur["W"]
-        h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], F_, Hc * Wc, mc, 1e-5)
-        oc = self.cfg["out_channels"]
-        if oc % 4:
-            raise ops._l.Hi3dError("out_channels must be a multiple of 4")
-        return ops.gemm(h, W["out.2.w"], M=F_ * Hc * Wc, N=oc, K=9 * mc, bias=W["out.2.b"], out_fp32=True,
-                        conv3x3=dict(Hin=Hc, Win=Wc, Cin=mc, Hout=Hc, Wout=Wc, stride=1, up2x=0))
+                return run(c, cur, h, layers, f"output_blocks.{i}", h2=s)
+            h = ops.concat_channels(h, s, c.F * cur["H"] * cur["W"], cur["C"], sc)
+            return run(c, cur, h, layers, f"output_blocks.{i}")
+
+        def head(c, cur, h, out):
+            Hc, Wc = cur["H"], cur["W"]
+            h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], c.F, Hc * Wc, mc, 1e-5)
+            return ops.gemm(h, W["out.2.w"], M=c.F * Hc * Wc, N=oc, K=9 * mc, bias=W["out.2.b"], out_fp32=True, out=out,
+                            conv3x3=dict(Hin=Hc, Win=Wc, Cin=mc, Hout=Hc, Wout=Wc, stride=1, up2x=0))
+
+        full = make_ctx(F_, emb_all, cond, a1_all, a_all, kw)
+        cur = {"H": H, "W": Wd, "C": CIN_PAD}
+        want_two = self.two_stream == "1" or (self.two_stream == "auto" and F_ * H * Wd >= (1 << 18))
+        n_split_in, n_split_out = self._split_plan() if (want_two and sp is None and B_all == 2 and F_ % 2 == 0) else (0, 0)
+        if not n_split_in:
+            h, hs = x_tok, []
+            for i, layers in enumerate(blocks_in):
+                h = run(full, cur, h, layers, f"input_blocks.{i}")
+                hs.append((h, cur["C"]))
+            h = run(full, cur, h, middle, "middle_block")
+            for i, layers in enumerate(blocks_out):
+                s, sc = hs.pop()
+                h = run_out_block(full, cur, h, i, layers, s, sc)
+            return head(full, cur, h, None)
+
+        # ---- the two CFG halves on two streams through the large levels (HI3D_TWO_STREAM).  The unconditional and the
+        # conditional half of the batch never mix inside the network (every op treats a clip / a frame by itself), so in the
+        # levels whose launches are large enough to split without loss the two halves run as two kernel sequences side by
+        # side: one half's launch tails and HBM-bound kernels are filled by the other half's work.  The small levels (whose
+        # half-batch launches would under-fill the chip) run joint on the main stream.  Cross-stream lifetimes: everything a
+        # stream allocates and frees stays in that stream's order; tensors made on one stream and read on the other (the
+        # joint activation at the second fork, emb_all, the per-clip constants) are held until the final join.
+        Fh = F_ // 2
+        for pt, Ct in self.transformers:             # lazily cached per-clip constants of the half-batch shape: made HERE, on the
+            self._pos_emb(pt, Ct, 1, T)              # main stream, before the fork (the two streams would race on the first fill)
+        main = torch.cuda.current_stream()
+        # per-kernel timing (ops.PROFILER: HIP events around every launch) wants kernels that do not share the chip: the two
+        # halves then run one after the other on the main stream -- same kernels, same shapes, no overlap
+        side = main if ops.PROFILER is not None else self._side_stream()
+        self.last_forward_two_stream = side is not main
+        halves = []
+        for hf in (0, 1):
+            fs = slice(hf * Fh, (hf + 1) * Fh)
+            cond_h = {k: (v[fs] if v.shape[0] == F_ else v[hf:hf + 1]) for k, v in cond.items()}
+            halves.append(make_ctx(Fh, emb_all[fs], cond_h, a1_all[:, fs], a_all[:, fs], dict(sp=None, B=1)))
+        rows = x_tok.shape[0] // 2
+        x_half = (x_tok[:rows], x_tok[rows:])
+        out = torch.empty((F_ * H * Wd, oc), device=x_tok.device, dtype=torch.float32)
+        hold = [emb_all, out]
+
+        def seg_in(hf):
+            cur_h = dict(cur)
+            h_, hs_ = x_half[hf], []
+            for i in range(n_split_in):
+                h_ = run(halves[hf], cur_h, h_, blocks_in[i], f"input_blocks.{i}")
+                hs_.append((h_, cur_h["C"]))
+            return h_, hs_, cur_h
+
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            h_c, hs_c, _ = seg_in(1)
+        h_u, hs_u, cur = seg_in(0)
+        main.wait_stream(side)
+        # joint middle: the halves become one batch again (the tensors at this point are small: the level below the split)
+        h = torch.cat((h_u, h_c), 0)
+        hs = [None] * n_split_in
+        if n_split_in:
+            hs[-1] = (h, cur["C"])                   # the last split block's output IS h (its down-sampling conv)
+        for i in range(n_split_in, len(blocks_in)):
+            h = run(full, cur, h, blocks_in[i], f"input_blocks.{i}")
+            hs.append((h, cur["C"]))
+        h = run(full, cur, h, middle, "middle_block")
+        n_joint_out = len(blocks_out) - n_split_out
+        for i in range(n_joint_out):
+            s, sc = hs.pop()
+            h = run_out_block(full, cur, h, i, blocks_out[i], s, sc)
+        hold.append(h)
+        hr = h.shape[0] // 2
+        h_half = (h[:hr], h[hr:])
+
+        def seg_out(hf, hs_):
+            cur_h = dict(cur)
+            h_ = h_half[hf]
+            for i in range(n_joint_out, len(blocks_out)):
+                s, sc = hs_.pop()
+                h_ = run_out_block(halves[hf], cur_h, h_, i, blocks_out[i], s, sc)
+            orows = out.shape[0] // 2
+            return head(halves[hf], cur_h, h_, out[hf * orows:(hf + 1) * orows])
+
+        hs_u.pop(); hs_c.pop()                      # (the last split block's output went into the joint part above)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            seg_out(1, hs_c)
+        seg_out(0, hs_u)
+        main.wait_stream(side)
+        del hold
+        return out
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    def _split_plan(self):
+        """(number of leading input blocks, number of trailing output blocks) that run as two half-batch sequences on two
+        streams: the blocks of the top `HI3D_TWO_STREAM_LEVELS` (default 2) resolution levels, including the down-sampling
+        block that leaves them; everything below runs joint."""
+        if self._plan is None:
+            blocks_in, middle, blocks_out = self.layout
+            nlev = int(os.environ.get("HI3D_TWO_STREAM_LEVELS", "2"))
+            lvl, n_in = 0, 0
+            for i, layers in enumerate(blocks_in):
+                if lvl < nlev:
+                    n_in = i + 1
+                if layers[0][0] == "down":
+                    lvl += 1
+            # output blocks: the level at a block's INPUT; an "up" layer at its end raises the level for the next block
+            lvl = len(self.cfg["channel_mult"]) - 1
+            n_out = 0
+            for i, layers in enumerate(blocks_out):
+                if lvl < nlev:
+                    n_out = len(blocks_out) - i
+                    break
+                if any(L[0] == "up" for L in layers):
+                    lvl -= 1
+            # the joint part must consume exactly the skip tensors it produced + the output of the last split block
+            ok = n_in and n_out and n_in < len(blocks_in) and (len(blocks_out) - n_out) == (len(blocks_in) - n_in) + 1
+            self._plan = (n_in, n_out) if ok else (0, 0)
+        return self._plan
 
     @torch.no_grad()
     def forward_nchw(self, x, timesteps, context, y, T, image_only_indicator):
