@@ -4,7 +4,7 @@
 #   rocprofv3 kernel-trace summary of the stage-2 bench, and PMC passes (separate runs, kernel trace only, as the
 #   pool requires): FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel) and two SQ passes (MFMA busy / VALU).
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ (tools/collect_profiles.sh).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -16,6 +16,13 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --s
 DB=$(ls /tmp/prof_kt/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats.csv 2> $O/s2_kernel_stats.txt
 rm -rf /tmp/prof_kt
+# round 4: the default command overlaps the two CFG halves of the large levels on two streams, so the kernel durations of
+# the trace above are those of kernels SHARING the chip (their sum exceeds the step).  The same command with one stream
+# (HI3D_TWO_STREAM=0: full-batch launches, nothing concurrent) gives the per-kernel durations free of overlap.
+HI3D_TWO_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt1 -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile --no-legs > $O/s2_bench_under_rocprof_one_stream.log 2>&1
+DB=$(ls /tmp/prof_kt1/*.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats_one_stream.csv 2> $O/s2_kernel_stats_one_stream.txt
+rm -rf /tmp/prof_kt1
 rocprofv3 -L > $O/rocprof_counters.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   HI3D_STEP_GRAPH=0 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o run --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-legs > $O/pmc_$c.log 2>&1
