@@ -622,8 +622,10 @@ def bench_vae(a, rank, world, dev, use_dist, steps, warmup):
     T, lat = a.views, 128
     z = torch.randn(T, 4, lat, lat, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
 
-    def clip():
-        return [ae.decode(z[i:i + 1]) for i in range(T)][-1]
+    from hi3d_hip import runtime_vae
+
+    def clip():     # (the chunk loop of DiffusionEngine.decode_first_stage: HI3D_VAE_STREAMS=2 alternates frames over two streams)
+        return runtime_vae.run_chunks(lambda lo, hi: ae.decode(z[lo:hi]), [(i, i + 1) for i in range(T)], dev)[-1]
 
     for _ in range(max(1, warmup)):
         out = clip()
@@ -650,7 +652,8 @@ def bench_vae(a, rank, world, dev, use_dist, steps, warmup):
            "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
            "ms_per_frame": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
-           "config": {"workload": f"AutoencoderKL decoder (ch 128, mult 1-2-4-4), {T} frames @ {lat * 8}x{lat * 8}, one frame per call"},
+           "config": {"workload": f"AutoencoderKL decoder (ch 128, mult 1-2-4-4), {T} frames @ {lat * 8}x{lat * 8}, one frame per call",
+                      "streams": 2 if runtime_vae.VAE_STREAMS >= 2 else 1},
            "roofline": {"bound": "mfma", "achieved": round(tf / (ms_frame / 1e3), 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / (ms_frame / 1e3) / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "note": f"{tf} algorithmic TFLOP per frame / wall time per frame"}}

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const CombineParams
 // to split with it claims -- a launch on any other stream finds no workspace and simply does not split (same result up to
 // the fp32 summation order, never a race).
 struct GemmWorkspace { void* ptr; long bytes; hipStream_t stream; bool any_stream, claimed; };
-constexpr int WS_SLOTS = 8;                       // per device: slot 0 = the stream-less registration
+constexpr int WS_SLOTS = 64;                      // per device: slot 0 = the stream-less registration (8 ran out in one pytest process: round 4)
 GemmWorkspace g_ws[HI3D_MAX_DEVICES][WS_SLOTS] = {};
 std::mutex g_ws_mu;
 // the workspace `stream` may use on `dev` (claims the stream-less one for it on first use), or nullptr

@@ -104,9 +104,18 @@ __global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_finalize_kernel(const fl
                                                                         double inv_count, float eps) {
   const int inst = blockIdx.x, tid = threadIdx.x & 63, part = threadIdx.x >> 6;
   __shared__ double sh[GN_FIN_PARTS][64];
-  double acc = 0.0;
-  for (int b = part; b < nblk; b += GN_FIN_PARTS) acc += (double)partial[((long)inst * nblk + b) * 64 + tid];
-  sh[part][tid] = acc;
+  // four loads in flight per thread (a 3-D norm fed by the producing conv's 64-row partials has nblk = T*H*W / 64 = 4096 blocks
+  // per instance and TWO instances: the one-load-at-a-time loop took 110 us there); fixed order, so still reproducible
+  const float* src = partial + (long)inst * nblk * 64 + tid;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = part;
+  for (; b + 3 * GN_FIN_PARTS < nblk; b += 4 * GN_FIN_PARTS) {
+    const float v0 = src[(long)b * 64], v1 = src[(long)(b + GN_FIN_PARTS) * 64];
+    const float v2 = src[(long)(b + 2 * GN_FIN_PARTS) * 64], v3 = src[(long)(b + 3 * GN_FIN_PARTS) * 64];
+    a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+  }
+  for (; b < nblk; b += GN_FIN_PARTS) a0 += (double)src[(long)b * 64];
+  sh[part][tid] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (part == 0) {
     double tot = 0.0;

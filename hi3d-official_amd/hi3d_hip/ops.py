@@ -132,7 +132,9 @@ def _ensure_gemm_workspace(dev, stream=None):
     if ws is not None:
         with torch.cuda.device(idx):
             rc = _lib.hi3d_gemm_set_workspace_for_stream(_p(ws), mb << 20, handle)
-        if rc != 0:          # all per-stream slots taken (a process cycling through many streams): this stream does not split
+        if rc != 0:          # all per-stream slots taken (a process cycling through > 63 streams): this stream does not split
+            import warnings
+            warnings.warn("hi3d: no split-K scratch slot left for this stream (63 per device); its long-K GEMMs run unsplit")
             ws = None
     _GEMM_WS[(idx, handle)] = ws
 

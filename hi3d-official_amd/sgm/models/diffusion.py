@@ -83,14 +83,16 @@ class DiffusionEngine(nn.Module):
 
     @torch.no_grad()
     def decode_first_stage(self, z):
+        from hi3d_hip.runtime_vae import run_chunks
         z = z * (1.0 / self.scale_factor)
-        outs = []
-        for lo, hi in self._chunks(z.shape[0]):
+
+        def one(lo, hi):
             kwargs = {}
             if getattr(self.first_stage_model, "is_video_decoder", False):
                 kwargs["timesteps"] = hi - lo
-            outs.append(self.first_stage_model.decode(z[lo:hi], **kwargs))
-        return torch.cat(outs, dim=0)
+            return self.first_stage_model.decode(z[lo:hi], **kwargs)
+
+        return torch.cat(run_chunks(one, self._chunks(z.shape[0]), z.device), dim=0)
 
     @torch.no_grad()
     def encode_first_stage_with_noise(self, x, noise=None):
@@ -99,5 +101,6 @@ class DiffusionEngine(nn.Module):
 
     @torch.no_grad()
     def encode_first_stage(self, x):
-        outs = [self.first_stage_model.encode(x[lo:hi]) for lo, hi in self._chunks(x.shape[0])]
+        from hi3d_hip.runtime_vae import run_chunks
+        outs = run_chunks(lambda lo, hi: self.first_stage_model.encode(x[lo:hi]), self._chunks(x.shape[0]), x.device)
         return self.scale_factor * torch.cat(outs, dim=0)

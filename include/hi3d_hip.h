@@ -129,7 +129,7 @@ int hi3d_gemm_set_workspace(void* ptr, int64_t bytes);
 /* The same, bound to ONE stream (round 4): split-K launches on `stream` of the current device use this buffer, launches on
  * other streams never do (they use their own registration, or the stream-less one above if they were the first to claim it,
  * or do not split) -- two GEMMs in flight on two streams cannot share partial tiles.  Register the stream a HIP graph is
- * CAPTURED on before capturing (the pointer is baked into the graph).  Up to 7 streams per device; ptr = NULL withdraws. */
+ * CAPTURED on before capturing (the pointer is baked into the graph).  Up to 63 streams per device; ptr = NULL withdraws. */
 int hi3d_gemm_set_workspace_for_stream(void* ptr, int64_t bytes, void* stream);
 /* debug aid (ISA-level timing stress, hi3d_hip/devtools/isa_stress.py): the launch hi3d_gemm_bf16(d) WOULD make, not made.
  * params_out (>= 512 bytes) <- the kernel argument; info[10] <- {its size, grid, block, dynamic LDS bytes, and the template

@@ -45,6 +45,39 @@ def test_engine_decode_first_stage_chunks(dev):
     assert rel < 4e-2
 
 
+def test_chunks_on_two_streams_equal_one_stream(dev, monkeypatch):
+    """Round 4: the chunk loop of decode_first_stage / encode_first_stage alternates chunks over two HIP streams
+    (runtime_vae.run_chunks).  Same launches on the same data: bit-identical to the one-stream loop, repeatedly (a race on a
+    shared scratch buffer or a missing join would show up as a difference), also for a full-width decoder with split-K
+    launches and for an odd number of chunks."""
+    from hi3d_hip import runtime_vae, synth
+    from sgm.models.autoencoder import AutoencoderKL
+    from sgm.models.diffusion import DiffusionEngine
+    for name, n in (("vae_tiny", 5), ("vae_full_lat8", 6)):
+        fx = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+        eng = DiffusionEngine.__new__(DiffusionEngine)
+        torch.nn.Module.__init__(eng)
+        eng.first_stage_model = AutoencoderKL(embed_dim=4, ddconfig=fx["ddconfig"])
+        synth.fill_module_(eng.first_stage_model, fx["weight_seed"], prefix=fx["key_prefix"])
+        eng.first_stage_model.to(dev)
+        eng.scale_factor, eng.en_and_decode_n_samples_a_time = 0.18215, 1
+        z0 = fx["z"].to(dev)
+        z = torch.cat([z0[:1] * (1.0 + 0.1 * i) for i in range(n)])
+        monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
+        ref = eng.decode_first_stage(z)
+        monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 2)
+        for _ in range(3):
+            out = eng.decode_first_stage(z)
+            assert torch.equal(out, ref), name
+        if name == "vae_tiny":                                  # the encoder's chunk loop (posterior .sample(): same noise order)
+            x = ref.clamp(-1, 1)
+            monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
+            torch.manual_seed(3); a = eng.encode_first_stage(x)
+            monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 2)
+            torch.manual_seed(3); b = eng.encode_first_stage(x)
+            assert a.shape == z.shape and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["vae_enc_tiny", "vae_enc_full_64"])
 def test_vae_encode_matches_reference_golden(dev, name):
     """Encoder + quant_conv + posterior: mode vs the reference mean, and sample with the

@@ -69,6 +69,28 @@ template <int ROLE> __device__ __forceinline__ float run(float seed) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) { bf2 r = __builtin_convertvector(f2{e[i], e[(i + 1) & 7]}, bf2); e[i] += (float)r[0]; }
     float s = 0; for (int i = 0; i < 8; ++i) s += e[i]; return s;
+  } else if (ROLE == 8 || ROLE == 9 || ROLE == 10 || ROLE == 11) {
+    // round 4: does a non-transcendental VALU instruction issue in the shadow of a v_exp_f32 of the SAME wave?  Fixed order
+    // (inline asm): 8 = exp / pk_fma alternating (4 + 4), 9 = the 4 exps alone, 10 = the 4 pk_fma alone, 11 = 4 exps then 4 pk_fma
+    float e[4]; f2 pf[4]; for (int i = 0; i < 4; ++i) { e[i] = seed * (i + 1); pf[i] = f2{seed * i, seed}; }
+    const f2 m = f2{1.0001f, 1.0002f}, c = f2{0.5f, 0.25f};
+    for (int it = 0; it < N; ++it) {
+      if (ROLE == 8)
+        asm volatile("v_exp_f32 %0, %0\n v_pk_fma_f32 %4, %4, %8, %9\n v_exp_f32 %1, %1\n v_pk_fma_f32 %5, %5, %8, %9\n"
+                     "v_exp_f32 %2, %2\n v_pk_fma_f32 %6, %6, %8, %9\n v_exp_f32 %3, %3\n v_pk_fma_f32 %7, %7, %8, %9"
+                     : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : "v"(m), "v"(c));
+      else if (ROLE == 9)
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3"
+                     : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+      else if (ROLE == 10)
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
+                     : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : "v"(m), "v"(c));
+      else
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                     "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9"
+                     : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : "v"(m), "v"(c));
+    }
+    float s = 0; for (int i = 0; i < 4; ++i) s += e[i] + pf[i][0] + pf[i][1]; return s;
   }
   return 0;
 }
@@ -105,5 +127,11 @@ int main() {
   go<0, 0>("wave A exp x8 | wave B exp x8", out);
   go<1, 1>("wave A fma x8 | wave B fma x8", out);
   go<3, 3>("both: mfma32 x4 + exp x8", out);
+  go<9, -1>("asm: exp x4", out);
+  go<10, -1>("asm: pk_fma x4", out);
+  go<8, -1>("asm: exp / pk_fma alternating (4 + 4)", out);
+  go<11, -1>("asm: exp x4 then pk_fma x4", out);
+  go<0, 4>("wave A exp x8 | wave B pk_fma x8", out);
+  go<9, 10>("wave A asm exp x4 | wave B asm pk_fma x4", out);
   return 0;
 }
