@@ -653,7 +653,7 @@ def bench_vae(a, rank, world, dev, use_dist, steps, warmup):
            "ms_per_frame": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
            "config": {"workload": f"AutoencoderKL decoder (ch 128, mult 1-2-4-4), {T} frames @ {lat * 8}x{lat * 8}, one frame per call",
-                      "streams": 2 if runtime_vae.VAE_STREAMS >= 2 else 1},
+                      "streams": max(1, min(runtime_vae.VAE_STREAMS, T))},
            "roofline": {"bound": "mfma", "achieved": round(tf / (ms_frame / 1e3), 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / (ms_frame / 1e3) / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "note": f"{tf} algorithmic TFLOP per frame / wall time per frame"}}

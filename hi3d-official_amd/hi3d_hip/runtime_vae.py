@@ -45,8 +45,8 @@ VAE_FLASH = os.environ.get("HI3D_VAE_FLASH", "0") == "1"
 
 
 # The chunks of a clip (decode_first_stage / encode_first_stage: `en_and_decode_n_samples_a_time` frames per call, 1 at stage 2)
-# are independent 2-D problems.  HI3D_VAE_STREAMS=2 (default) issues them alternately on the caller's stream and on one side
-# stream, so that the HBM-bound launches of one frame (GroupNorm: 20 % of a frame, the score softmax) share the chip with the
+# are independent 2-D problems.  HI3D_VAE_STREAMS=n (default 2) issues them round-robin on the caller's stream and n - 1 side
+# streams, so that the HBM-bound launches of one frame (GroupNorm: 20 % of a frame, the score softmax) share the chip with the
 # MFMA-bound convolutions of the other and the tails of one frame's short launches are filled by the other's.  Each stream has
 # its own split-K / GroupNorm scratch (ops keys them by stream); results are the same launches on the same data.
 VAE_STREAMS = int(os.environ.get("HI3D_VAE_STREAMS", "2"))
@@ -54,27 +54,30 @@ _SIDE = {}
 
 
 def run_chunks(fn, chunks, device):
-    """[fn(lo, hi) for lo, hi in chunks], odd chunks on a side stream (joined before returning); fn returns one tensor."""
+    """[fn(lo, hi) for lo, hi in chunks], chunk i on stream i % VAE_STREAMS (0 = the caller's; the side streams are joined before
+    returning); fn returns one tensor."""
     dev = torch.device(device)
-    if (dev.type != "cuda" or VAE_STREAMS < 2 or len(chunks) < 2 or ops.PROFILER is not None
-            or torch.cuda.is_current_stream_capturing()):       # (per-kernel timing wants kernels that do not share the chip)
-        return [fn(lo, hi) for lo, hi in chunks]
+    n = min(VAE_STREAMS, len(chunks))
+    if dev.type != "cuda" or n < 2 or ops.PROFILER is not None or torch.cuda.is_current_stream_capturing():
+        return [fn(lo, hi) for lo, hi in chunks]                 # (per-kernel timing wants kernels that do not share the chip)
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream()
-        side = _SIDE.get(dev.index)
-        if side is None:
-            side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
-        side.wait_stream(main)                                   # the latents were produced on the caller's stream
+        pool = _SIDE.setdefault(dev.index, [])
+        while len(pool) < n - 1:
+            pool.append(torch.cuda.Stream(device=dev))
+        for side in pool[:n - 1]:
+            side.wait_stream(main)                               # the latents were produced on the caller's stream
         outs = []
         for i, (lo, hi) in enumerate(chunks):
-            if i % 2 == 0:
+            if i % n == 0:
                 outs.append(fn(lo, hi))
             else:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(pool[i % n - 1]):
                     o = fn(lo, hi)
                 o.record_stream(main)                            # allocated in the side stream's pool, consumed on `main`
                 outs.append(o)
-        main.wait_stream(side)
+        for side in pool[:n - 1]:
+            main.wait_stream(side)
     return outs
 
 

@@ -65,10 +65,11 @@ def test_chunks_on_two_streams_equal_one_stream(dev, monkeypatch):
         z = torch.cat([z0[:1] * (1.0 + 0.1 * i) for i in range(n)])
         monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
         ref = eng.decode_first_stage(z)
-        monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 2)
-        for _ in range(3):
-            out = eng.decode_first_stage(z)
-            assert torch.equal(out, ref), name
+        for ns in (2, 3, 2):
+            monkeypatch.setattr(runtime_vae, "VAE_STREAMS", ns)
+            for _ in range(2):
+                out = eng.decode_first_stage(z)
+                assert torch.equal(out, ref), (name, ns)
         if name == "vae_tiny":                                  # the encoder's chunk loop (posterior .sample(): same noise order)
             x = ref.clamp(-1, 1)
             monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
