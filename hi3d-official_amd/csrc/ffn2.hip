@@ -41,6 +41,8 @@ struct Ffn2Params {
   const unsigned short* R1; const unsigned short* R2; const float* a1; const float* a2;
   unsigned short* out;
   int M, ldx, ldo, ldr1, ldr2, rpg;
+  // LN = true (hi3d_ffn_geglu_ln): X is the RAW residual stream; the kernel normalises the rows itself
+  const float* ln_g; const float* ln_b; const float* av; float ln_eps; int rpg_av;
 };
 
 constexpr int GC = 320;                    // channels
@@ -57,7 +59,16 @@ constexpr int G1D = 2;                     // first GEMM: fragment pairs in flig
 constexpr int G2D = 3;                     // second GEMM: W2 fragments in flight (of the 10 per phase)
 constexpr int FFN2_LDS = 2 * W1S + 2 * W2H + HGB + B1B + X9B;      // 157,696 B
 
+// LN: the LayerNorm in front of the feed-forward (x = ff(norm3(x)) + x, attention.py:570; x = ff_in(norm_in(x)) + x and
+// x = ff(norm3(x)) + x, video_attention.py:119-133) runs in the prologue on the X registers: a lane holds 80 of its row's 320
+// channels (the 4 lanes fr + 16 fg share a row), so the statistics are two register passes + two cross-lane adds, and the
+// normalised bf16 values replace the raw ones in place -- layernorm_packed_kernel's arithmetic (fp32, mean first, then the
+// centred sum of squares), its rounding points, and the optional per-row-group vector (the frame-position embedding,
+// video_attention.py:276-283: statistics on the UNROUNDED sum, the residual takes bf16(x + vector)).  Removes the norm's
+// launch, its read of x and its write of the normalised tensor (and, with the vector, the write of the sum).
+template <int LNM>       // 0: X is already normalised; 1: LayerNorm in the prologue; 2: ... of x + per-row-group vector
 __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Params p) {
+  constexpr bool LN = LNM != 0, AV = LNM == 2;
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sW1 = smem;                                   // stage A at 0, stage B at W1S
@@ -79,6 +90,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // k = 32*kk + 8*fg .. +7)
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)m0 * p.ldx * 2), 0, 0x7fffffff, 0x00020000);
   bf16x8 xr[9][2];
+  u32x4 x9raw[2];                                           // (LN: channels 288..319 pass through registers too)
   const int x9_off = wmg * 1024 + lane * 16;                // + mt * 4096
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -86,7 +98,23 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     const unsigned vo = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + fg * 16) : INV;
 #pragma unroll
     for (int kk = 0; kk < 9; ++kk) xr[kk][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0));
-    if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
+    if (!LN) {
+      if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
+    } else {
+      x9raw[mt] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
+    }
+  }
+  if (LN) {      // gamma | beta into the hg slab (free until the first GELU; read after the prologue barrier)
+    float* const sG = (float*)sHG;
+    if (tid < GC / 4) *(f32x4*)(sG + tid * 4) = *(const f32x4*)(p.ln_g + tid * 4);
+    else if (tid < GC / 2) *(f32x4*)(sG + GC + (tid - GC / 4) * 4) = *(const f32x4*)(p.ln_b + (tid - GC / 4) * 4);
+    else if (AV && tid < GC) {
+      // ... and the (at most two: rows_per_group >= 128, checked by the host) vectors the block's 128 rows belong to
+      const int t = tid - GC / 2, which = t / (GC / 4), c4 = t % (GC / 4);
+      const int g0 = m0 / p.rpg_av, glast = (p.M - 1) / p.rpg_av;
+      const int g = g0 + which < glast ? g0 + which : glast;
+      *(f32x4*)(sG + (2 + which) * GC + c4 * 4) = *(const f32x4*)(p.av + (long)g * GC + c4 * 4);
+    }
   }
 
   // ---- weight loaders.  W1 stage = 40 pieces of 1 KiB (8 packed rows x 128 B of one K slab): wave w moves row group w
@@ -134,11 +162,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
     return sHG + hg_off + mt * 2048 + ((((stage * 4 + wn * 2 + (fg >> 1))) ^ f_sw) << 4) + (fg & 1) * 8;
   };
 
-  f32x4 acc2[2][10];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 10; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[2][10];                               // (zeroed right in front of the loop: the LayerNorm prologue needs the registers)
   f32x4 acc1[2][2];
 
   // value * gelu(gate) of one 16-row block of a stage's accumulators -> 4 hidden columns per lane -> hg
@@ -229,6 +253,82 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   issue_w1(0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the bias copy and the X slab are plain LDS stores)
   __builtin_amdgcn_s_barrier();
+  if (LN) {
+    // ---- LayerNorm of the wave's 32 rows in place.  Both column halves normalise their own copy of a row (the same data in
+    // the same order: the same result).  Three passes over the packed registers, one 16-row block at a time -- the 80 fp32
+    // values of a lane's row share are never held at once (they spilled).
+    const float* const sG = (const float*)sHG;
+    int avo[2];                                    // this lane's first element of its rows' vectors
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int r = wmg * 32 + mt * 16 + fr;
+      const int row = (m0 + r < p.M) ? m0 + r : 0;
+      avo[mt] = AV ? ((2 + (row / p.rpg_av != m0 / p.rpg_av)) * GC + fg * 8) * 4 : 0;     // byte offset into the staged vectors
+    }
+    auto vals = [&](int kk, int mt, float (&f)[8]) {
+      u32x4 q = kk < 9 ? __builtin_bit_cast(u32x4, xr[kk < 9 ? kk : 0][mt]) : x9raw[mt];
+      int ao = avo[mt];
+      asm volatile("" : "+v"(q), "+v"(ao));          // (opaque: otherwise the values of pass 1 are kept for passes 2 and 3 -- spills)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(q[j] << 16); f[2 * j + 1] = __uint_as_float(q[j] & 0xffff0000u); }
+      if (AV) {
+        const char* ap = (const char*)sG + ao + kk * 128;
+        const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
+      }
+    };
+    // Every step of the three passes ends in an empty volatile asm on its result: volatile asms keep their order, so a step's
+    // loads / unpacking cannot be hoisted over the previous step and its arithmetic cannot be deferred past the next one --
+    // left to itself the scheduler read all 80 gamma / beta values (and all vector values) first and spilled ~100-280 registers.
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float sm = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 10; ++kk) {
+        float f[8]; vals(kk, mt, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm += f[j];
+        asm volatile("" : "+v"(sm));
+      }
+      sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+      mean[mt] = sm * (1.0f / (float)GC);
+      float ss = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 10; ++kk) {
+        float f[8]; vals(kk, mt, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = f[j] - mean[mt]; ss += d * d; }
+        asm volatile("" : "+v"(ss));
+      }
+      ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+      rstd[mt] = rsqrtf(ss * (1.0f / (float)GC) + p.ln_eps);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 10; ++kk) {               // gamma / beta of a channel block once for both 16-row blocks
+      int go = (kk * 32 + fg * 8) * 4;
+      asm volatile("" : "+v"(go));
+      const char* gp = (const char*)sG + go;
+      const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 16), b0 = *(const f32x4*)(gp + GC * 4), b1 = *(const f32x4*)(gp + GC * 4 + 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float f[8]; vals(kk, mt, f);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (f[j] - mean[mt]) * rstd[mt] * g0[j] + b0[j];
+          o[4 + j] = (f[4 + j] - mean[mt]) * rstd[mt] * g1[j] + b1[j];
+        }
+        u32x4 pk = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        asm volatile("" : "+v"(pk));
+        if (kk < 9) xr[kk < 9 ? kk : 0][mt] = __builtin_bit_cast(bf16x8, pk);
+        else if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = pk;     // (no LDS-DMA outstanding here: the first W1 stage was waited for)
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // the X slab and the last reads of gamma / beta, before any hg store
+  }
   if (late) __builtin_amdgcn_s_barrier();          // the stagger
 
   // One loop iteration = one HALF chunk hc (32 hidden columns = 64 packed W1 rows; slot s = hc & 1 of every ring).
@@ -246,6 +346,10 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // segment of phase k+2 at the earliest, and a wave waits for its own pieces in the load segment one phase before the
   // first reader (the other group reads one barrier later).  hg rows belong to one group (both column halves of a
   // 32-row block are in the same half of the block), so its hazards are plain program order plus any barrier.
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NHC = 2 * GNCH;
   for (int hc = 0; hc <= NHC; ++hc) {
     const bool cur = hc < NHC, prev = hc > 0;
@@ -339,7 +443,16 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
       const int grp = (p.a1 || p.a2) ? (int)(m / p.rpg) : 0;
       const float s1 = p.a1 ? p.a1[grp] : 1.0f;
       const float s2 = p.a2 ? p.a2[grp] : 1.0f;
-      const u32x4 r1 = q1[mt][i], r2 = q2[mt][i];
+      u32x4 r1 = q1[mt][i];
+      const u32x4 r2 = q2[mt][i];
+      if (AV) {                                      // the residual is bf16(x + vector), as layernorm's sum_out rounded it
+        const float* a = p.av + (long)((int)m / p.rpg_av) * GC + n;
+        const f32x4 a0 = *(const f32x4*)a, a1 = *(const f32x4*)(a + 4);
+        const float av8[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          r1[j] = pack_bf16x2(__uint_as_float(r1[j] << 16) + av8[2 * j], __uint_as_float(r1[j] & 0xffff0000u) + av8[2 * j + 1]);
+      }
       float v[8] = {lo[0] + b0[0], lo[1] + b0[1], lo[2] + b0[2], lo[3] + b0[3], hi[0] + b1[0], hi[1] + b1[1], hi[2] + b1[2], hi[3] + b1[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -359,6 +472,18 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
 }  // namespace
 
 // entry point shared with ffn.hip: hi3d_ffn_geglu() dispatches here unless HI3D_FFN_V=1
+template <int LNM>
+static int ffn2_launch_t(const Ffn2Params& p, void* stream) {
+  static bool attr_done[HI3D_MAX_DEVICES] = {};
+  if (int rc = hi3d_raise_lds_limit((const void*)ffn2_geglu_c320_kernel<LNM>, FFN2_LDS, attr_done)) return rc;
+  hipLaunchKernelGGL(ffn2_geglu_c320_kernel<LNM>, dim3((p.M + GBM - 1) / GBM), dim3(512), FFN2_LDS, (hipStream_t)stream, p);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+static int ffn2_launch(const Ffn2Params& p, bool ln, void* stream) {
+  return !ln ? ffn2_launch_t<0>(p, stream) : p.av ? ffn2_launch_t<2>(p, stream) : ffn2_launch_t<1>(p, stream);
+}
+
 int hi3d_ffn2_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                      const void* r1, const void* r2, const float* a1, const float* a2, void* out,
                      int32_t M, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2, int32_t rows_per_group, void* stream) {
@@ -367,9 +492,34 @@ int hi3d_ffn2_launch(const void* x, const void* w1, const float* b1, const void*
   p.R1 = (const unsigned short*)r1; p.R2 = (const unsigned short*)r2; p.a1 = a1; p.a2 = a2;
   p.out = (unsigned short*)out; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr1 = ldr1; p.ldr2 = ldr2;
   p.rpg = rows_per_group < 1 ? 1 : rows_per_group;
-  static bool attr_done[HI3D_MAX_DEVICES] = {};
-  if (int rc = hi3d_raise_lds_limit((const void*)ffn2_geglu_c320_kernel, FFN2_LDS, attr_done)) return rc;
-  hipLaunchKernelGGL(ffn2_geglu_c320_kernel, dim3((M + GBM - 1) / GBM), dim3(512), FFN2_LDS, (hipStream_t)stream, p);
-  HI3D_LAUNCH_CHECK();
-  return HI3D_OK;
+  p.ln_g = nullptr; p.ln_b = nullptr; p.av = nullptr; p.ln_eps = 0.f; p.rpg_av = 1;
+  return ffn2_launch(p, false, stream);
+}
+
+extern "C" int hi3d_ffn_geglu_ln(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                 const float* addvec, int32_t addvec_rows_per_group,
+                                 const void* w1, const float* b1, const void* w2, const float* b2,
+                                 const void* r1, const void* r2, const float* a1, const float* a2, void* out,
+                                 int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
+                                 int32_t rows_per_group, void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w1 || !b1 || !w2 || !b2 || !out) HI3D_FAIL(HI3D_EINVAL, "ffn_geglu_ln: null pointer");
+  if (M <= 0) HI3D_FAIL(HI3D_EINVAL, "ffn_geglu_ln: non-positive M");
+  if (C != GC) HI3D_FAIL(HI3D_ESHAPE, "ffn_geglu_ln: only the 320-channel level is fused (layernorm + two GEMMs otherwise)");
+  if (ldx < C || ldo < C || (ldx % 8) || (ldo % 4)) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu_ln: bad ldx / ldo");
+  if ((r1 && (ldr1 < C || ldr1 % 4)) || (r2 && (ldr2 < C || ldr2 % 4))) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu_ln: bad residual leading dim");
+  if ((a1 || a2) && rows_per_group < 1) HI3D_FAIL(HI3D_EINVAL, "ffn_geglu_ln: rows_per_group < 1");
+  if (addvec && addvec_rows_per_group < GBM)
+    HI3D_FAIL(HI3D_ESHAPE, "ffn_geglu_ln: addvec_rows_per_group must be >= 128 (a 128-row block stages at most two vectors)");
+  if (addvec && !r1) HI3D_FAIL(HI3D_EINVAL, "ffn_geglu_ln: addvec is added to the normalised input AND to the residual r1 -- r1 missing");
+  if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2) & 15) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu_ln: x / w1 / w2 not 16-byte aligned");
+  if (((uintptr_t)out | (uintptr_t)r1 | (uintptr_t)r2) & 7) HI3D_FAIL(HI3D_EALIGN, "ffn_geglu_ln: out / residuals not 8-byte aligned");
+  if (((uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)addvec) & 15)
+    HI3D_FAIL(HI3D_EALIGN, "ffn_geglu_ln: biases / layernorm vectors / addvec not 16-byte aligned");
+  Ffn2Params p;
+  p.X = (const char*)x; p.W1 = (const char*)w1; p.b1 = b1; p.W2 = (const char*)w2; p.b2 = b2;
+  p.R1 = (const unsigned short*)r1; p.R2 = (const unsigned short*)r2; p.a1 = a1; p.a2 = a2;
+  p.out = (unsigned short*)out; p.M = M; p.ldx = ldx; p.ldo = ldo; p.ldr1 = ldr1; p.ldr2 = ldr2;
+  p.rpg = rows_per_group < 1 ? 1 : rows_per_group;
+  p.ln_g = ln_gamma; p.ln_b = ln_beta; p.av = addvec; p.ln_eps = ln_eps; p.rpg_av = addvec ? addvec_rows_per_group : 1;
+  return ffn2_launch(p, true, stream);
 }

@@ -669,17 +669,34 @@ def time_mix_small(x, w, b, B, T, H, W, C):
 FFN_FUSED_WIDTHS = (320,)   # channel counts hi3d_ffn_geglu is built for
 
 
-def ffn_geglu(x, w1, b1, w2, b2, *, M, C, R1=None, R2=None, a1=None, a2=None, rows_per_group=1, out=None):
+LN_FUSED = os.environ.get("HI3D_LN_FUSED", "1") != "0"   # the LayerNorm in front of a fused feed-forward runs inside its launch
+
+
+def ffn_geglu(x, w1, b1, w2, b2, *, M, C, R1=None, R2=None, a1=None, a2=None, rows_per_group=1, out=None,
+              ln=None, addvec=None, addvec_rows_per_group=1):
     """out[M, C] = (GEGLU(x w1^T + b1) w2^T + b2 + R1) [* a1 + a2 * R2] with the 4C hidden tensor kept on
-    the CU (one launch instead of the GEGLU GEMM + the second GEMM).  See include/hi3d_hip.h."""
-    _chk_dev(x, w1, b1, w2, b2, R1, R2, a1, a2, out)
+    the CU (one launch instead of the GEGLU GEMM + the second GEMM).  See include/hi3d_hip.h.
+    ln = (gamma, beta, eps): x is the raw residual stream and the kernel normalises its rows first (hi3d_ffn_geglu_ln);
+    addvec [groups, C] fp32 is then added to x before the norm and to the residual R1 (the frame-position embedding)."""
+    _chk_dev(x, w1, b1, w2, b2, R1, R2, a1, a2, out, addvec)
     if out is None:
         out = torch.empty((M, C), device=x.device, dtype=torch.bfloat16)
     prof = PROFILER
     t0 = prof.begin() if prof else None
-    _l.check(_lib.hi3d_ffn_geglu(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(R1), _p(R2), _p(a1), _p(a2), _p(out),
-                                 M, C, x.stride(0), out.stride(0), R1.stride(0) if R1 is not None else 0,
-                                 R2.stride(0) if R2 is not None else 0, rows_per_group, _stream()), "hi3d_ffn_geglu")
+    if ln is not None:
+        g, b, eps = ln
+        _chk_dev(x, g, b)
+        assert g.dtype == torch.float32 and b.dtype == torch.float32 and (addvec is None or addvec.dtype == torch.float32)
+        assert addvec is None or (addvec.is_contiguous() and addvec.shape[-1] == C)
+        _l.check(_lib.hi3d_ffn_geglu_ln(_p(x), _p(g), _p(b), float(eps), _p(addvec), int(addvec_rows_per_group),
+                                        _p(w1), _p(b1), _p(w2), _p(b2), _p(R1), _p(R2), _p(a1), _p(a2), _p(out),
+                                        M, C, x.stride(0), out.stride(0), R1.stride(0) if R1 is not None else 0,
+                                        R2.stride(0) if R2 is not None else 0, rows_per_group, _stream()), "hi3d_ffn_geglu_ln")
+    else:
+        assert addvec is None
+        _l.check(_lib.hi3d_ffn_geglu(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(R1), _p(R2), _p(a1), _p(a2), _p(out),
+                                     M, C, x.stride(0), out.stride(0), R1.stride(0) if R1 is not None else 0,
+                                     R2.stride(0) if R2 is not None else 0, rows_per_group, _stream()), "hi3d_ffn_geglu")
     if prof:
         nres = (R1 is not None) + (R2 is not None)
         prof.end("ffn_fused", 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C,

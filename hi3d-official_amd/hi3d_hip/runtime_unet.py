@@ -340,8 +340,7 @@ class UNetRuntime:
             ops.self_attention_fused_qkv(qkv, F_, S, Hh, q_prescaled=True)
         h = ops.gemm(a, W[sp_ + ".o.w"], M=M, N=C, K=C, bias=W[sp_ + ".o.b"], R1=h,
                      rowvec=cond[sp_], rows_per_group=S)                    # + attn1 + attn2 (one token)
-        n = ops.layernorm(h, W[sp_ + ".norm3.g"], W[sp_ + ".norm3.b"], M, C)
-        h = self._ff(n, sp_ + ".ff", M, C, R1=h)
+        h = self._ln_ff(h, sp_ + ".norm3", sp_ + ".ff", M, C)
         # --- temporal block (video_attention.py:109-140): rows stay in (b t) s order -- or, frame-parallel,
         # become (b t s_local) through the all-to-all
         St = S
@@ -349,22 +348,35 @@ class UNetRuntime:
             St = S // sp.world
             h = sp.frames_to_space(h, B, S)
         Mt = B * T * St
-        xm = torch.empty_like(h)
-        n = ops.layernorm(h, W[tp + ".norm_in.g"], W[tp + ".norm_in.b"], Mt, C, addvec=self._pos_emb(p, C, B, T),
-                          rows_per_group=St, sum_out=xm)                     # xm = h + frame-position emb
-        xm = self._ff(n, tp + ".ff_in", Mt, C, R1=xm)
+        # xm = h + frame-position emb;  xm = ff_in(norm_in(xm)) + xm
+        xm = self._ln_ff(h, tp + ".norm_in", tp + ".ff_in", Mt, C, addvec=self._pos_emb(p, C, B, T), addvec_rows_per_group=St)
         n = ops.layernorm(xm, W[tp + ".norm1.g"], W[tp + ".norm1.b"], Mt, C)
         qkv = ops.gemm(n, W[tp + ".qkv.w"], M=Mt, N=3 * C, K=C)
         a = ops.attention_temporal_fused_qkv(qkv, B, T, St, Hh)
         xm = ops.gemm(a, W[tp + ".o.w"], M=Mt, N=C, K=C, bias=W[tp + ".o.b"], R1=xm,
                       rowvec=cond[tp], rows_per_group=T * St)
-        n = ops.layernorm(xm, W[tp + ".norm3.g"], W[tp + ".norm3.b"], Mt, C)
         i = self.mix_index[p]
-        # AlphaBlender: alpha*h + (1-alpha)*(ff(..)+xm)                      (video_attention.py:290-294)
-        h = self._ff(n, tp + ".ff", Mt, C, R1=xm, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=St)
+        # AlphaBlender: alpha*h + (1-alpha)*(ff(norm3(xm))+xm)               (video_attention.py:290-294)
+        h = self._ln_ff(xm, tp + ".norm3", tp + ".ff", Mt, C, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=St)
         if sp is not None:
             h = sp.space_to_frames(h, B, S)
         return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x)
+
+    def _ln_ff(self, x, nkey, fkey, M, C, addvec=None, addvec_rows_per_group=1, **epi):
+        """x' = x [+ addvec per row group];  ff(LayerNorm(x')) + x' [blend epilogue].  Where the feed-forward is the fused
+        launch (C = 320) the norm runs inside it (hi3d_ffn_geglu_ln: x' and the normalised tensor never exist); otherwise
+        hi3d_layernorm (which also writes x') and the GEMM pair."""
+        W = self.W
+        g, b = W[nkey + ".g"], W[nkey + ".b"]
+        if C in ops.FFN_FUSED_WIDTHS and self.fused_ffn and ops.LN_FUSED and (addvec is None or addvec_rows_per_group >= 128):
+            return ops.ffn_geglu(x, W[fkey + ".1.w"], W[fkey + ".1.b"], W[fkey + ".2.w"], W[fkey + ".2.b"], M=M, C=C, R1=x,
+                                 ln=(g, b, 1e-5), addvec=addvec, addvec_rows_per_group=addvec_rows_per_group, **epi)
+        if addvec is None:
+            n, r = ops.layernorm(x, g, b, M, C), x
+        else:
+            r = torch.empty_like(x)
+            n = ops.layernorm(x, g, b, M, C, addvec=addvec, rows_per_group=addvec_rows_per_group, sum_out=r)
+        return self._ff(n, fkey, M, C, R1=r, **epi)
 
     def _ff(self, n, key, M, C, **epi):
         """FeedForward(glu=True) (attention.py:83-119) + the caller's residual / blend epilogue: one fused

@@ -430,6 +430,21 @@ int hi3d_ffn_geglu(const void* x, const void* w1, const float* b1, const void* w
                    int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
                    int32_t rows_per_group, void* stream);
 
+/* The same with the LayerNorm in front of it inside the launch (round 4):
+ *   n   = LayerNorm(x [+ addvec[row / addvec_rows_per_group]]) * ln_gamma + ln_beta     (fp32 statistics over the C channels)
+ *   out = ( GEGLU(n W1^T + b1) W2^T + b2 + r1' ) [ * a1 + a2 * r2 ]          r1' = r1, or bf16(r1 + addvec[...]) with addvec
+ * -- x = ff(norm3(x)) + x of BasicTransformerBlock (sgm/modules/attention.py:570) and x = ff_in(norm_in(x)) + x /
+ * x = ff(norm3(x)) + x of VideoTransformerBlock (sgm/modules/video_attention.py:119-133); addvec [groups][C] fp32 is the
+ * frame-position embedding SpatialVideoTransformer adds in front of the temporal block (video_attention.py:276-283), which
+ * then never exists as a tensor.  x is the RAW residual stream (normally r1 == x).  Same arithmetic and rounding points as
+ * hi3d_layernorm followed by hi3d_ffn_geglu (summation order of the statistics differs); C == 320 only.            */
+int hi3d_ffn_geglu_ln(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                      const float* addvec, int32_t addvec_rows_per_group,
+                      const void* w1, const float* b1, const void* w2, const float* b2,
+                      const void* r1, const void* r2, const float* a1, const float* a2, void* out,
+                      int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
+                      int32_t rows_per_group, void* stream);
+
 /* out = in.permute(perm) for a 4-D array of rows: in[dims[0]][dims[1]][dims[2]][dims[3]][row_bytes] (row_bytes % 16 == 0),
  * out[dims[perm[0]]][dims[perm[1]]][dims[perm[2]]][dims[perm[3]]][row_bytes].  The pack / unpack around the frame <-> space
  * all-to-all of one clip on several GPUs (the reference has no inference parallelism, README.md:56-64):
