@@ -90,19 +90,24 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   // k = 32*kk + 8*fg .. +7)
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)m0 * p.ldx * 2), 0, 0x7fffffff, 0x00020000);
   bf16x8 xr[9][2];
-  u32x4 x9raw[2];                                           // (LN: channels 288..319 pass through registers too)
+  u32x4 mine[10];                                           // (LN: the raw 16-row block this wave normalises, all 320 channels)
   const int x9_off = wmg * 1024 + lane * 16;                // + mt * 4096
+  if (!LN) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int r = wmg * 32 + mt * 16 + fr;
+    for (int mt = 0; mt < 2; ++mt) {
+      const int r = wmg * 32 + mt * 16 + fr;
+      const unsigned vo = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + fg * 16) : INV;
+#pragma unroll
+      for (int kk = 0; kk < 9; ++kk) xr[kk][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0));
+      if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
+    }
+  } else {
+    // the two waves of a 32-row block (column halves wn = 0, 1) each fetch and normalise ONE of its 16-row blocks (mt = wn)
+    // and hand the result to each other through LDS
+    const int r = wmg * 32 + wn * 16 + fr;
     const unsigned vo = (m0 + r < p.M) ? (unsigned)(r * p.ldx * 2 + fg * 16) : INV;
 #pragma unroll
-    for (int kk = 0; kk < 9; ++kk) xr[kk][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0));
-    if (!LN) {
-      if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
-    } else {
-      x9raw[mt] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 9 * 64, 0);
-    }
+    for (int kk = 0; kk < 10; ++kk) mine[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, kk * 64, 0);
   }
   if (LN) {      // gamma | beta into the hg slab (free until the first GELU; read after the prologue barrier)
     float* const sG = (float*)sHG;
@@ -254,21 +259,22 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the bias copy and the X slab are plain LDS stores)
   __builtin_amdgcn_s_barrier();
   if (LN) {
-    // ---- LayerNorm of the wave's 32 rows in place.  Both column halves normalise their own copy of a row (the same data in
-    // the same order: the same result).  Three passes over the packed registers, one 16-row block at a time -- the 80 fp32
-    // values of a lane's row share are never held at once (they spilled).
+    // ---- LayerNorm of this wave's 16 rows (three passes over the packed registers: the 80 fp32 values of a lane's row share
+    // are never held at once), normalised bf16 fragments -> the exchange slab (the second W1 slot and the W2 ring: idle until
+    // the loop's first requests, which come after the barriers below) / the X slab; then both waves of the pair read the whole
+    // 32-row tile from there.
+    // Every step ends in an empty volatile asm on its result: volatile asms keep their order, so a step's loads / unpacking
+    // cannot be hoisted over the previous step and its arithmetic cannot be deferred past the next one -- left to itself the
+    // scheduler read all 80 gamma / beta values first and spilled ~100-280 registers.
     const float* const sG = (const float*)sHG;
-    int avo[2];                                    // this lane's first element of its rows' vectors
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int r = wmg * 32 + mt * 16 + fr;
-      const int row = (m0 + r < p.M) ? m0 + r : 0;
-      avo[mt] = AV ? ((2 + (row / p.rpg_av != m0 / p.rpg_av)) * GC + fg * 8) * 4 : 0;     // byte offset into the staged vectors
-    }
-    auto vals = [&](int kk, int mt, float (&f)[8]) {
-      u32x4 q = kk < 9 ? __builtin_bit_cast(u32x4, xr[kk < 9 ? kk : 0][mt]) : x9raw[mt];
-      int ao = avo[mt];
-      asm volatile("" : "+v"(q), "+v"(ao));          // (opaque: otherwise the values of pass 1 are kept for passes 2 and 3 -- spills)
+    char* const xchg = sW1 + W1S;                            // [wmg][mt][kk < 9][lane] x 16 B = 72 KiB of the 80 free
+    const int r = wmg * 32 + wn * 16 + fr;
+    const int row = (m0 + r < p.M) ? m0 + r : 0;
+    const int avo = AV ? ((2 + (row / p.rpg_av != m0 / p.rpg_av)) * GC + fg * 8) * 4 : 0;     // byte offset into the staged vectors
+    auto vals = [&](int kk, float (&f)[8]) {
+      u32x4 q = mine[kk];
+      int ao = avo;
+      asm volatile("" : "+v"(q), "+v"(ao));
 #pragma unroll
       for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(q[j] << 16); f[2 * j + 1] = __uint_as_float(q[j] & 0xffff0000u); }
       if (AV) {
@@ -278,57 +284,55 @@ __global__ __launch_bounds__(512, 2) void ffn2_geglu_c320_kernel(const Ffn2Param
         for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
       }
     };
-    // Every step of the three passes ends in an empty volatile asm on its result: volatile asms keep their order, so a step's
-    // loads / unpacking cannot be hoisted over the previous step and its arithmetic cannot be deferred past the next one --
-    // left to itself the scheduler read all 80 gamma / beta values (and all vector values) first and spilled ~100-280 registers.
-    float mean[2], rstd[2];
+    float sm = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float sm = 0.f;
+    for (int kk = 0; kk < 10; ++kk) {
+      float f[8]; vals(kk, f);
 #pragma unroll
-      for (int kk = 0; kk < 10; ++kk) {
-        float f[8]; vals(kk, mt, f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sm += f[j];
-        asm volatile("" : "+v"(sm));
-      }
-      sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
-      mean[mt] = sm * (1.0f / (float)GC);
-      float ss = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 10; ++kk) {
-        float f[8]; vals(kk, mt, f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = f[j] - mean[mt]; ss += d * d; }
-        asm volatile("" : "+v"(ss));
-      }
-      ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-      rstd[mt] = rsqrtf(ss * (1.0f / (float)GC) + p.ln_eps);
+      for (int j = 0; j < 8; ++j) sm += f[j];
+      asm volatile("" : "+v"(sm));
     }
+    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm * (1.0f / (float)GC);
+    float ss = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 10; ++kk) {               // gamma / beta of a channel block once for both 16-row blocks
+    for (int kk = 0; kk < 10; ++kk) {
+      float f[8]; vals(kk, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; ss += d * d; }
+      asm volatile("" : "+v"(ss));
+    }
+    ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+    const float rstd = rsqrtf(ss * (1.0f / (float)GC) + p.ln_eps);
+    char* const my_x = xchg + (wmg * 2 + wn) * 9 * 1024 + lane * 16;
+#pragma unroll
+    for (int kk = 0; kk < 10; ++kk) {
       int go = (kk * 32 + fg * 8) * 4;
       asm volatile("" : "+v"(go));
       const char* gp = (const char*)sG + go;
       const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 16), b0 = *(const f32x4*)(gp + GC * 4), b1 = *(const f32x4*)(gp + GC * 4 + 16);
+      float f[8]; vals(kk, f);
+      float o[8];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        float f[8]; vals(kk, mt, f);
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[j] = (f[j] - mean[mt]) * rstd[mt] * g0[j] + b0[j];
-          o[4 + j] = (f[4 + j] - mean[mt]) * rstd[mt] * g1[j] + b1[j];
-        }
-        u32x4 pk = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        asm volatile("" : "+v"(pk));
-        if (kk < 9) xr[kk < 9 ? kk : 0][mt] = __builtin_bit_cast(bf16x8, pk);
-        else if (wn == 0) *(u32x4*)(sX9 + mt * 4096 + x9_off) = pk;     // (no LDS-DMA outstanding here: the first W1 stage was waited for)
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (f[j] - mean) * rstd * g0[j] + b0[j];
+        o[4 + j] = (f[4 + j] - mean) * rstd * g1[j] + b1[j];
       }
+      u32x4 pk = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      asm volatile("" : "+v"(pk));
+      // (plain LDS stores: no LDS-DMA is outstanding here -- the first W1 stage was waited for above)
+      if (kk < 9) *(u32x4*)(my_x + kk * 1024) = pk;
+      else *(u32x4*)(sX9 + (wn ? 4096 : 0) + x9_off) = pk;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                  // the X slab and the last reads of gamma / beta, before any hg store
-  }
+    __builtin_amdgcn_s_barrier();                  // both 16-row blocks of every pair are in LDS
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kk = 0; kk < 9; ++kk) xr[kk][mt] = *(const bf16x8*)(xchg + ((wmg * 2 + mt) * 9 + kk) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // the exchange slab and gamma / beta are free again (the loop's first LDS-DMA
+  }                                                // into them and the first hg store come later)
   if (late) __builtin_amdgcn_s_barrier();          // the stagger
 
   // One loop iteration = one HALF chunk hc (32 hidden columns = 64 packed W1 rows; slot s = hc & 1 of every ring).

@@ -264,7 +264,7 @@ def test_ffn_geglu_with_the_layernorm_inside(dev, mode):
     same = (out == two).float().mean().item()
     print(f"ffn with the norm inside ({mode}): rel vs fp32 {relerr(out, ref):.2e}, vs layernorm + ffn {relerr(out, two.float()):.2e}, "
           f"{100 * same:.2f} % of the outputs bit-identical")
-    assert relerr(out, two.float()) < 4e-3 and same > 0.97
+    assert relerr(out, two.float()) < 8e-3 and same > 0.97          # (one bf16 step of a normalised value moves an output by ~4e-3)
     for _ in range(5):                                  # repeatable
         assert torch.equal(ops.ffn_geglu(xd, *Wd, M=M, C=C, R1=xd, ln=(gd, bd, 1e-5), addvec=avd, addvec_rows_per_group=rav, **kw), out)
     with pytest.raises(ops._l.Hi3dError):               # the vector is part of the residual: no residual, no vector
