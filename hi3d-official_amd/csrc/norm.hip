@@ -96,40 +96,36 @@ __global__ void gn_stats_kernel(const uint4* __restrict__ x, const uint4* __rest
   if (tid < 64) partial[((long)inst * nblk + blk) * 64 + tid] = gs[tid];
 }
 
-// one block per instance: thread = (part, group, {sum|sumsq}); 16 parts walk the partials
-// in a fixed interleave, then a fixed-order fp64 combine (bitwise reproducible)
-constexpr int GN_FIN_PARTS = 16;
-__global__ __launch_bounds__(64 * GN_FIN_PARTS) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                                        float* __restrict__ stats, int nblk,
-                                                                        double inv_count, float eps) {
-  const int inst = blockIdx.x, tid = threadIdx.x & 63, part = threadIdx.x >> 6;
-  __shared__ double sh[GN_FIN_PARTS][64];
-  // four loads in flight per thread (a 3-D norm fed by the producing conv's 64-row partials has nblk = T*H*W / 64 = 4096 blocks
-  // per instance and TWO instances: the one-load-at-a-time loop took 110 us there); fixed order, so still reproducible
-  const float* src = partial + (long)inst * nblk * 64 + tid;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int b = part;
-  for (; b + 3 * GN_FIN_PARTS < nblk; b += 4 * GN_FIN_PARTS) {
-    const float v0 = src[(long)b * 64], v1 = src[(long)(b + GN_FIN_PARTS) * 64];
-    const float v2 = src[(long)(b + 2 * GN_FIN_PARTS) * 64], v3 = src[(long)(b + 3 * GN_FIN_PARTS) * 64];
-    a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+// one block per (instance, group): 256 threads walk the partial blocks in a fixed interleave (four 8-byte loads in flight each),
+// fp64, then a fixed-order tree -- bitwise reproducible.  (Rounds 1-3 ran ONE block per instance; with the producing conv's
+// 64-row partials a 3-D norm has 4096 partial blocks per instance and two instances: 110 us on two CUs.)
+constexpr int GN_FIN_PARTS = 16;        // (gn_reduce_kernel below: the sharded form keeps the one-block-per-instance walk)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk,
+                                                          double inv_count, float eps) {
+  const int g = blockIdx.x, inst = blockIdx.y, t = threadIdx.x;
+  const float2* src = (const float2*)(partial + (long)inst * nblk * 64) + g;       // block b: + 32 b
+  double s = 0.0, q = 0.0;
+  int b = t;
+  for (; b + 768 < nblk; b += 1024) {
+    const float2 v0 = src[(long)b * 32], v1 = src[(long)(b + 256) * 32], v2 = src[(long)(b + 512) * 32], v3 = src[(long)(b + 768) * 32];
+    s += (double)v0.x; q += (double)v0.y; s += (double)v1.x; q += (double)v1.y;
+    s += (double)v2.x; q += (double)v2.y; s += (double)v3.x; q += (double)v3.y;
   }
-  for (; b < nblk; b += GN_FIN_PARTS) a0 += (double)src[(long)b * 64];
-  sh[part][tid] = (a0 + a1) + (a2 + a3);
+  for (; b < nblk; b += 256) { const float2 v = src[(long)b * 32]; s += (double)v.x; q += (double)v.y; }
+  __shared__ double shs[256], shq[256];
+  shs[t] = s; shq[t] = q;
   __syncthreads();
-  if (part == 0) {
-    double tot = 0.0;
 #pragma unroll
-    for (int q = 0; q < GN_FIN_PARTS; ++q) tot += sh[q][tid];
-    sh[0][tid] = tot;
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { shs[t] += shs[t + o]; shq[t] += shq[t + o]; }
+    __syncthreads();
   }
-  __syncthreads();
-  if (part == 0 && (tid & 1) == 0) {
-    const double mean = sh[0][tid] * inv_count;
-    double var = sh[0][tid + 1] * inv_count - mean * mean;
+  if (t == 0) {
+    const double mean = shs[0] * inv_count;
+    double var = shq[0] * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
-    stats[inst * 64 + tid] = (float)mean;
-    stats[inst * 64 + tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[inst * 64 + 2 * g] = (float)mean;
+    stats[inst * 64 + 2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -377,7 +373,7 @@ int groupnorm_launch(const void* x, const void* x2, int C1, void* y, const float
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, (const uint4*)x2, C1 / 8, partial, P, C, nblk, ppb);
   HI3D_LAUNCH_CHECK();
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, partial, stats, nblk, inv_count, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, inst), dim3(256), 0, s, partial, stats, nblk, inv_count, eps);
   HI3D_LAUNCH_CHECK();
   const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
   const int ablk = (P + appb - 1) / appb;
@@ -408,7 +404,7 @@ extern "C" int hi3d_groupnorm_silu_from_partials(const void* x, void* y, const f
   const int nblk = P / 64;                               // == hi3d_gn_partial_blocks(P, C): the stats slot sits right behind
   float* stats = ws + (long)inst * nblk * 64;
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(inst), dim3(64 * GN_FIN_PARTS), 0, s, ws, stats, nblk, inv_count, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, inst), dim3(256), 0, s, ws, stats, nblk, inv_count, eps);
   HI3D_LAUNCH_CHECK();
   const int ppb = gn_ppb(inst, P);
   const int appb = ppb < GN_APPLY_PPB ? ppb : GN_APPLY_PPB;
