@@ -91,6 +91,7 @@ class UNetRuntime:
         # "auto" (default): when the top level has >= 2^18 token rows (stage 2 at 1024^2: measured -2.0 ms of 204.9 per step;
         # stage 1 at 512^2 loses 0.4 of 45.1 ms: its half-batch launches under-fill the chip); 1 = always, 0 = never
         self.two_stream = os.environ.get("HI3D_TWO_STREAM", "auto")
+        self.two_stream_lag = int(os.environ.get("HI3D_TWO_STREAM_LAG", "0"))
         self._side, self._plan = None, None
         self.last_forward_two_stream = False
         self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
@@ -456,6 +457,8 @@ class UNetRuntime:
                     h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
                     cur["H"], cur["W"] = 2 * Hc, 2 * Wc
+                if L[0] in ("res", "attn") and getattr(c, "after_layer", None) is not None:
+                    c.after_layer()                  # (two-stream lag: the other half may be started here)
             return h
 
         def run_out_block(c, cur, h, i, layers, s, sc):
@@ -520,11 +523,38 @@ class UNetRuntime:
                 hs_.append((h_, cur_h["C"]))
             return h_, hs_, cur_h
 
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            h_c, hs_c, _ = seg_in(1)
-        h_u, hs_u, cur = seg_in(0)
-        main.wait_stream(side)
+        # HI3D_TWO_STREAM_LAG=n: the second half starts when the first has issued n ResBlock / transformer layers of the
+        # segment -- started together the two halves run the same kind of kernel at the same time (both in a GroupNorm, both in
+        # attention); offset, one half's HBM-bound kernels meet the other's matrix-core kernels more often.
+        lag = self.two_stream_lag
+        fork = {"n": 0, "go": None}
+
+        def after_layer():
+            fork["n"] += 1
+            if fork["go"] is not None and fork["n"] >= lag:
+                go, fork["go"] = fork["go"], None
+                go()
+        halves[0].after_layer = after_layer if lag > 0 else None
+
+        def forked(seg_side, seg_main):
+            """run seg_side() on the side stream and seg_main() on the main stream, the side one `lag` layers behind"""
+            res = {}
+
+            def go():
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    res["side"] = seg_side()
+            fork["n"], fork["go"] = 0, go
+            if lag <= 0:
+                after_layer()
+            res["main"] = seg_main()
+            if fork["go"] is not None:               # (a segment shorter than the lag)
+                fork["go"] = None
+                go()
+            main.wait_stream(side)
+            return res["side"], res["main"]
+
+        (h_c, hs_c, _), (h_u, hs_u, cur) = forked(lambda: seg_in(1), lambda: seg_in(0))
         # joint middle: the halves become one batch again (the tensors at this point are small: the level below the split)
         h = torch.cat((h_u, h_c), 0)
         hs = [None] * n_split_in
@@ -552,11 +582,7 @@ class UNetRuntime:
             return head(halves[hf], cur_h, h_, out[hf * orows:(hf + 1) * orows])
 
         hs_u.pop(); hs_c.pop()                      # (the last split block's output went into the joint part above)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            seg_out(1, hs_c)
-        seg_out(0, hs_u)
-        main.wait_stream(side)
+        forked(lambda: seg_out(1, hs_c), lambda: seg_out(0, hs_u))
         del hold
         return out
 
