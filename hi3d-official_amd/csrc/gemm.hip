@@ -158,7 +158,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(DENSE2 ? p.A2 + (long)m0 * p.lda2 * 2 : a_origin), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.W + (long)n0 * p.ldw * 2 + (AMODE == HI3D_A_DENSE ? (long)ks * nk * (BK * 2) : 0L)), 0, 0x7fffffff, 0x00020000);
+      (void*)(p.W + (long)n0 * p.ldw * 2 + (AMODE == HI3D_A_DENSE ? (long)ks * nk * (BK * 2) : 0L) +
+              (p.wgs ? (long)(m0 / p.rpg) * p.wgs * 2 : 0L)),     // (per-row-group weights: the tile lies inside ONE group)
+      0, 0x7fffffff, 0x00020000);
 
   // conv modes: current tap and channel offset of the K chunk (split-K starts at a slab boundary: nk is a multiple of the taps)
   int tap = 0, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) * BK;
@@ -972,6 +974,12 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW; p.pad = d->pad_br_only ? 0 : 1;
   p.A2 = (const char*)d->A2; p.lda2 = d->lda2; p.K1 = d->K1;
+  p.wgs = d->w_group_stride;
+  if (p.wgs) {
+    if (p.wgs < 0 || p.wgs % 8) HI3D_FAIL(HI3D_EALIGN, "gemm: w_group_stride must be a non-negative multiple of 8 elements");
+    if (d->rows_per_group % 256 || d->M % d->rows_per_group)
+      HI3D_FAIL(HI3D_ESHAPE, "gemm: per-group weights need rows_per_group % 256 == 0 (the tallest tile) and M % rows_per_group == 0");
+  }
   p.gn_part = nullptr; g_gn_fused = 0;
   const bool two = d->A2 != nullptr;
   if (two) {

@@ -384,7 +384,57 @@ int groupnorm_launch(const void* x, const void* x2, int C1, void* y, const float
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }
+// ---- GroupNorm (no activation) folded into the following linear layer: one block per (output row n, instance f)
+//   Wf[f][n][k] = bf16(W[n][k] * a[f][k]),  biasf[f][n] = bias[n] + sum_k W[n][k] * b[f][k]     a = rstd * gamma, b = beta - mean * a
+// 64 threads walk the C input channels in a fixed interleave, fixed-order wave reduction: reproducible.
+__global__ __launch_bounds__(64) void gn_fold_linear_kernel(const unsigned short* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ stats, unsigned short* __restrict__ Wf,
+                                                            float* __restrict__ biasf, int C, int N) {
+  const int n = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C >> 5;
+  const unsigned short* wr = W + (long)n * ldw;
+  unsigned short* wo = Wf + ((long)f * N + n) * C;
+  float acc = 0.f;
+  for (int k = lane * 2; k < C; k += 128) {                   // two channels per lane and sweep (C % 32 == 0: even)
+    const unsigned int wp = *(const unsigned int*)(wr + k);
+    const float w0 = bf16_to_f32(wp & 0xffff), w1 = bf16_to_f32(wp >> 16);
+    const float* st0 = stats + f * 64 + (k / cpg) * 2;
+    const float* st1 = stats + f * 64 + ((k + 1) / cpg) * 2;
+    const float a0 = st0[1] * gamma[k], a1 = st1[1] * gamma[k + 1];
+    const float b0 = beta[k] - st0[0] * a0, b1 = beta[k + 1] - st1[0] * a1;
+    *(unsigned int*)(wo + k) = pack_bf16x2(w0 * a0, w1 * a1);
+    acc += w0 * b0 + w1 * b1;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) biasf[(long)f * N + n] = acc + (bias ? bias[n] : 0.f);
+}
+
 }  // namespace
+
+extern "C" int hi3d_groupnorm_fold_linear(const void* x, float* ws, const float* gamma, const float* beta, float eps,
+                                          int32_t inst, int32_t P, int32_t C, const void* W, int32_t ldw, const float* bias,
+                                          int32_t N, void* Wf, float* biasf, void* stream) {
+  if (!x || !ws || !gamma || !beta || !W || !Wf || !biasf) HI3D_FAIL(HI3D_EINVAL, "groupnorm_fold_linear: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0 || N <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm_fold_linear: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (ldw < C || ldw % 2) HI3D_FAIL(HI3D_EALIGN, "groupnorm_fold_linear: ldw < C or odd");
+  if (((uintptr_t)x & 15) || ((uintptr_t)W & 3) || ((uintptr_t)Wf & 15)) HI3D_FAIL(HI3D_EALIGN, "groupnorm_fold_linear: misaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int ppb = gn_ppb(inst, P);
+  const int nblk = (P + ppb - 1) / ppb;
+  const int nthr = gn_threads(C);
+  float* stats = ws + (long)inst * nblk * 64;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, inst), dim3(nthr), nthr * 16 * sizeof(float), s, (const uint4*)x, (const uint4*)nullptr, 0, ws, P, C, nblk, ppb);
+  HI3D_LAUNCH_CHECK();
+  const double inv_count = 1.0 / ((double)P * (double)(C / 32));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, inst), dim3(256), 0, s, ws, stats, nblk, inv_count, eps);
+  HI3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(N, inst), dim3(64), 0, s, (const unsigned short*)W, ldw, bias, gamma, beta, stats,
+                     (unsigned short*)Wf, biasf, C, N);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
 
 extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
                                    float* ws, int32_t inst, int32_t P, int32_t C, float eps,

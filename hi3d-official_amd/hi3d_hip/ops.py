@@ -74,7 +74,7 @@ def _chk_dev(*ts):
 
 def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, w_group_stride=0):
     """(hi3d_gemm_desc, out) of gemm(...) with the same arguments -- built, not launched (gemm() launches it; the ISA stress
     tool hands it to hi3d_debug_gemm_launch_info).  out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
@@ -100,6 +100,7 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
     d.epi = _l.EPI_GEGLU if geglu else _l.EPI_AFFINE
     d.out_fp32 = 1 if out_fp32 else 0
     d.tile_n = tile_n
+    d.w_group_stride = int(w_group_stride)
     if conv3x3 is not None:
         d.amode = _l.A_CONV3X3
         for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "up2x"):
@@ -141,7 +142,7 @@ def _ensure_gemm_workspace(dev, stream=None):
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, gn=None):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, gn=None, w_group_stride=0):
     """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
@@ -152,7 +153,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     cannot provide them (the caller then runs the plain groupnorm_silu)."""
     d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
                        a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n,
-                       A2=A2, K1=K1, lda2=lda2)
+                       A2=A2, K1=K1, lda2=lda2, w_group_stride=w_group_stride)
     _ensure_gemm_workspace(A.device)
     n_out = N // 2 if geglu else N
     gn_ws = None
@@ -399,6 +400,30 @@ def groupnorm_silu_sharded(x, gamma, beta, inst, P, C, eps, allreduce_, world, s
                                             int(world) * P * (C // 32), float(eps), 1 if silu else 0, _stream()),
              "hi3d_groupnorm_apply_sums")
     return out
+
+
+# HI3D_GN_FOLD=1: the transformer's GroupNorm as a per-frame rescaling of proj_in's weights.  Opt-in: it removes the norm's apply
+# pass (GroupNorm family 9.85 -> 9.40 ms per stage-2 step) but the step's wall time does not move (198.96 / 198.69 vs 198.49 /
+# 199.12 ms: those passes already ran under the other CFG half's matrix-core kernels) -- profiles/r04s_gn_fold_ab.log
+GN_FOLD = os.environ.get("HI3D_GN_FOLD", "0") == "1"
+
+
+def groupnorm_fold_linear(x, gamma, beta, inst, P, C, eps, W, bias, N):
+    """The statistics of GroupNorm(32; no activation) over x [inst * P, C] folded into the linear layer (W [N, C] bf16 K-major,
+    bias [N] fp32 or None) that consumes the normalised tensor: returns (Wf [inst, N, C] bf16, biasf [inst, N] fp32) for
+    gemm(x, Wf, ..., rowvec=biasf, rows_per_group=P, w_group_stride=N * C).  See include/hi3d_hip.h."""
+    _chk_dev(x, gamma, beta, W, bias)
+    assert W.dtype == torch.bfloat16 and W.is_contiguous() and W.shape[-1] == C and W.shape[0] == N
+    ws = _gn_workspace(x.device, inst, P, C)
+    Wf = torch.empty((inst, N, C), device=x.device, dtype=torch.bfloat16)
+    biasf = torch.empty((inst, N), device=x.device, dtype=torch.float32)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_groupnorm_fold_linear(_p(x), _p(ws), _p(gamma), _p(beta), float(eps), inst, P, C, _p(W), C, _p(bias), N,
+                                             _p(Wf), _p(biasf), _stream()), "hi3d_groupnorm_fold_linear")
+    if prof:
+        prof.end("groupnorm_silu", 0.0, 2.0 * inst * P * C, t0)
+    return Wf, biasf
 
 
 def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum_out=None, out=None):

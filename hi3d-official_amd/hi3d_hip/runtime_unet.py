@@ -331,8 +331,16 @@ class UNetRuntime:
         W, M, Hh = self.W, F_ * S, C // 64
         B = F_ // T if B is None else B
         sp_, tp = p + ".transformer_blocks.0", p + ".time_stack.0"
-        xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False)
-        h = self._linear(xn, p + ".proj_in", M)
+        if ops.GN_FOLD and S % 256 == 0:
+            # norm (GroupNorm eps 1e-6, no activation) + proj_in: the norm is a per-(frame, channel) scale and shift, i.e. a
+            # per-frame rescaling of proj_in's weights and bias -- statistics pass + a tiny fold kernel, then the GEMM reads the
+            # RAW x with frame f's weights; the normalised tensor is never written (attention.py:702-712)
+            Wf, bf_ = ops.groupnorm_fold_linear(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6,
+                                                W[p + ".proj_in.w"], W[p + ".proj_in.b"], C)
+            h = ops.gemm(x, Wf, M=M, N=C, K=C, rowvec=bf_, rows_per_group=S, w_group_stride=C * C)
+        else:
+            xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False)
+            h = self._linear(xn, p + ".proj_in", M)
         # --- spatial block (attention.py:551-572)
         n = ops.layernorm(h, W[sp_ + ".norm1.g"], W[sp_ + ".norm1.b"], M, C)
         qkv = ops.gemm(n, W[sp_ + ".qkv.w"], M=M, N=3 * C, K=C)

@@ -115,6 +115,12 @@ typedef struct hi3d_gemm_desc {
    * workspace with 64-pixel blocks -- so the GroupNorm that follows (openaimodel.py:292-294 `out_layers` after the
    * `in_layers` conv; the time_stack likewise) reads the tensor once (hi3d_groupnorm_silu_from_partials). */
   float* gn_partial;
+  /* One weight matrix per row group (round 4; 0 = one shared W): rows [g * rows_per_group, (g + 1) * rows_per_group) multiply
+   * W + g * w_group_stride elements.  The transformer's GroupNorm(eps 1e-6, no SiLU) in front of proj_in
+   * (sgm/modules/attention.py:702-712) is a per-(frame, channel) scale and shift, i.e. a per-frame rescaling of proj_in's
+   * weights and bias (hi3d_groupnorm_fold_linear) -- the normalised tensor is then never written.  rows_per_group must be a
+   * multiple of the tile height (256) and divide M. */
+  int64_t w_group_stride;
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);
@@ -444,6 +450,17 @@ int hi3d_ffn_geglu_ln(const void* x, const float* ln_gamma, const float* ln_beta
                       const void* r1, const void* r2, const float* a1, const float* a2, void* out,
                       int32_t M, int32_t C, int32_t ldx, int32_t ldo, int32_t ldr1, int32_t ldr2,
                       int32_t rows_per_group, void* stream);
+
+/* GroupNorm(32 groups; no activation) folded into the linear layer that follows it:
+ *   y = GN(x) W^T + bias,  GN(x)[r][k] = x[r][k] * a[f][k] + b[f][k]   (f = instance of row r; a = rstd * gamma, b = beta - mean * a)
+ *     = x (W .* a[f])^T + (bias + W b[f])
+ * Runs the statistics passes of hi3d_groupnorm_silu on x [inst * P, C] (ws as there) and writes, per instance,
+ *   Wf[f][n][k] = bf16(W[n][k] * a[f][k])   [inst][N][C]      biasf[f][n] = bias[n] + sum_k W[n][k] * b[f][k]   [inst][N] fp32
+ * for hi3d_gemm_bf16(A = x, W = Wf, w_group_stride = N * C, rowvec = biasf, rows_per_group = P).  W: bf16 [N][ldw] K-major;
+ * bias may be NULL.  Reference: SpatialTransformer.norm + proj_in, sgm/modules/attention.py:702-712.                       */
+int hi3d_groupnorm_fold_linear(const void* x, float* ws, const float* gamma, const float* beta, float eps,
+                               int32_t inst, int32_t P, int32_t C, const void* W, int32_t ldw, const float* bias, int32_t N,
+                               void* Wf, float* biasf, void* stream);
 
 /* out = in.permute(perm) for a 4-D array of rows: in[dims[0]][dims[1]][dims[2]][dims[3]][row_bytes] (row_bytes % 16 == 0),
  * out[dims[perm[0]]][dims[perm[1]]][dims[perm[2]]][dims[perm[3]]][row_bytes].  The pack / unpack around the frame <-> space

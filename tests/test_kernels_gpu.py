@@ -464,6 +464,36 @@ def test_gemm_split_k_scratch_is_per_stream(dev):
         L.check(lib.hi3d_gemm_set_workspace(None, 0), "hi3d_gemm_set_workspace")
 
 
+def test_groupnorm_folded_into_the_linear_layer(dev):
+    """Round 4: SpatialTransformer.norm (GroupNorm 32, eps 1e-6, no activation) + proj_in (attention.py:702-712) as a
+    per-frame rescaling of proj_in's weights and bias (hi3d_groupnorm_fold_linear) + a GEMM with one weight matrix per row
+    group (hi3d_gemm_desc.w_group_stride) on the RAW x: vs fp32 torch and vs hi3d_groupnorm_silu + hi3d_gemm_bf16."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_linear
+    inst, P, C = 3, 512, 320
+    x = bf(rnd((inst * P, C), 301, 1.5) + rnd((1, C), 302, 2.0))          # (per-channel offsets: non-trivial group means)
+    g, b = rnd((C,), 303).abs() + 0.5, rnd((C,), 304, 0.3)
+    w, bias = bf(rnd((C, C), 305, C ** -0.5)).float(), rnd((C,), 306)
+    xn = F.group_norm(x.float().reshape(inst, P, C).permute(0, 2, 1), 32, g, b, 1e-6).permute(0, 2, 1).reshape(inst * P, C)
+    ref = xn @ w.T + bias
+    xd, gd, bd, wd, biasd = x.to(dev), g.to(dev), b.to(dev), pack_linear(w).to(dev), bias.to(dev)
+    Wf, bf_ = ops.groupnorm_fold_linear(xd, gd, bd, inst, P, C, 1e-6, wd, biasd, C)
+    out = ops.gemm(xd, Wf, M=inst * P, N=C, K=C, rowvec=bf_, rows_per_group=P, w_group_stride=C * C)
+    two = ops.gemm(ops.groupnorm_silu(xd, gd, bd, inst, P, C, 1e-6, silu=False), wd, M=inst * P, N=C, K=C, bias=biasd)
+    print(f"GroupNorm folded into proj_in: rel vs fp32 {relerr(out, ref):.2e}, vs groupnorm + gemm {relerr(out, two.float()):.2e}")
+    assert relerr(out, ref) < BF16_TOL and relerr(out, two.float()) < 8e-3
+    for _ in range(3):
+        W2, b2 = ops.groupnorm_fold_linear(xd, gd, bd, inst, P, C, 1e-6, wd, biasd, C)
+        assert torch.equal(W2, Wf) and torch.equal(b2, bf_)
+    # the narrow tile too (N = 64 < 320: variant 0), no bias
+    w3 = bf(rnd((64, C), 307, C ** -0.5)).float()
+    W3, b3 = ops.groupnorm_fold_linear(xd, gd, bd, inst, P, C, 1e-6, pack_linear(w3).to(dev), None, 64)
+    out3 = ops.gemm(xd, W3, M=inst * P, N=64, K=C, rowvec=b3, rows_per_group=P, w_group_stride=64 * C)
+    assert relerr(out3, xn @ w3.T) < BF16_TOL
+    with pytest.raises(ops._l.Hi3dError):               # a tile must lie inside one group
+        ops.gemm(xd, Wf, M=inst * P, N=C, K=C, rowvec=bf_, rows_per_group=384, w_group_stride=C * C)
+
+
 @pytest.mark.parametrize("inst,P,C1,C2,silu", [(3, 100, 64, 64, True), (2, 777, 320, 640, True), (2, 64, 1280, 1280, False),
                                                  (1, 4096, 640, 320, True), (4, 9, 8, 56, True)])
 def test_groupnorm_cat2(dev, inst, P, C1, C2, silu):

@@ -303,6 +303,15 @@ def test_unet_skip_concat_in_place_equals_materialised(dev, monkeypatch, name):
     rel, c = stats(new, sep)
     print(f"{name}: producer-side GroupNorm statistics vs separate passes: rel {rel:.2e} cos {c:.6f}")
     assert rel < 1e-2
+    # HI3D_GN_FOLD=1 (opt-in): the transformer's GroupNorm as a per-frame rescaling of proj_in's weights -- the weights, not the
+    # activations, take the bf16 rounding of the scale: same network to rounding noise (tokens per frame % 256 == 0 only)
+    monkeypatch.setattr(ops, "GN_FUSED", True)
+    monkeypatch.setattr(ops, "GN_FOLD", True)
+    fold = run(build_unet(fx, dev))
+    rel, c = stats(new, fold)
+    ref = fx["output"].to(dev) if "output" in fx else None
+    print(f"{name}: GroupNorm folded into proj_in vs the norm pass: rel {rel:.2e} cos {c:.6f}")
+    assert rel < 2e-2 and c > 0.9998
 
 
 @pytest.mark.parametrize("how", ["new_tensor", "in_place"])
