@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       0, 0x7fffffff, 0x00020000);
 
   // conv modes: current tap and channel offset of the K chunk (split-K starts at a slab boundary: nk is a multiple of the taps)
-  int tap = 0, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) * BK;
+  int tap = 0, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? p.ntap : 3)) * BK;
 
   // LDS-DMA pieces [LO, HI) of K chunk `kt` into ring slot `st`: pieces 0..3 are this wave's A rows, 4.. its W rows
   // (the ping-pong loop spreads the pieces of a stage over its phases; the plain loops issue them all at once)
@@ -171,11 +171,14 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
     char* sA = smem + st * STAGE;
     char* sB = sA + A_BYTES;
-    unsigned soff;                                 // scalar byte offset of this K chunk
+    unsigned soff = 0;                             // scalar byte offset of this K chunk
     bool second = false;                           // DENSE2: this chunk lies in the second source (block-uniform)
     if (DENSE2) { const int kc = (kt0 + kt) * BK; second = kc >= p.K1; soff = (second ? kc - p.K1 : kc) * 2; }
     else if (AMODE == HI3D_A_DENSE) soff = kt * (BK * 2);
-    else if (AMODE == HI3D_A_CONV3X3) soff = UP2X ? c0 * 2 : (((tap / 3) * p.Win + (tap % 3)) * p.Cin + c0) * 2;
+    // (tap subset: the k-th K slab of a channel block reads image tap p.taps[k]; its weights are slab k of W)
+    const int tp = (AMODE == HI3D_A_CONV3X3 && !UP2X && p.taps) ? (int)((p.taps >> (4 * tap)) & 15u) : tap;
+    if (DENSE2 || AMODE == HI3D_A_DENSE) {}
+    else if (AMODE == HI3D_A_CONV3X3) soff = UP2X ? c0 * 2 : (((tp / 3) * p.Win + (tp % 3)) * p.Cin + c0) * 2;
     else soff = (tap * p.HW * p.Cin + c0) * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         const bool in = iy >= 0 && ix >= 0 && iy < 2 * p.Hin && ix < 2 * p.Win;
         vo = (in && vo != INV) ? vo + (unsigned)(((iy >> 1) * p.Win + (ix >> 1)) * p.Cin * 2) : INV;
       } else if (AMODE != HI3D_A_DENSE) {
-        vo = ((a_mask[i] >> tap) & 1) ? vo : INV;
+        vo = ((a_mask[i] >> tp) & 1) ? vo : INV;
       }
       if (DENSE2 && second)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (LDS_AS void*)(sA + (w * 4 + i) * 1024), 16, a_voff2[i], soff, 0, 0);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // HBM / the fabric once and the other taps hit L2.  (Round 1 walked taps outermost and re-fetched the
   // input per tap: FETCH_SIZE 6.5x the algorithmic bytes.)
   auto advance_k = [&]() {
-    if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? 9 : 3)) { tap = 0; c0 += BK; } }
+    if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? p.ntap : 3)) { tap = 0; c0 += BK; } }
   };
   auto issue = [&](int kt, int st) {
     issue_pieces(kt, st, std::integral_constant<int, 0>{}, std::integral_constant<int, 4 + W_PIECES>{});
@@ -974,6 +977,8 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.stride = d->stride; p.up2x = d->up2x; p.T = d->T; p.HW = d->HW; p.pad = d->pad_br_only ? 0 : 1;
   p.A2 = (const char*)d->A2; p.lda2 = d->lda2; p.K1 = d->K1;
+  p.ntap = (d->amode == HI3D_A_CONV3X3 && d->conv_ntap > 0) ? d->conv_ntap : 9;
+  p.taps = (d->amode == HI3D_A_CONV3X3 && d->conv_ntap > 0) ? d->conv_taps : 0u;
   p.wgs = d->w_group_stride;
   if (p.wgs) {
     if (p.wgs < 0 || p.wgs % 8) HI3D_FAIL(HI3D_EALIGN, "gemm: w_group_stride must be a non-negative multiple of 8 elements");
@@ -990,7 +995,12 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   } else if (d->amode == HI3D_A_DENSE) {
     if (d->lda < d->K || (d->lda % 8)) HI3D_FAIL(HI3D_EALIGN, "gemm: lda < K or lda % 8 != 0");
   } else if (d->amode == HI3D_A_CONV3X3) {
-    if (d->Cin <= 0 || d->Cin % 64 || d->K != 9 * d->Cin) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: need Cin % 64 == 0 and K == 9*Cin");
+    const int ntap = d->conv_ntap > 0 ? d->conv_ntap : 9;
+    if (d->conv_ntap < 0 || d->conv_ntap > 8) HI3D_FAIL(HI3D_EINVAL, "conv3x3: conv_ntap must be 0 (all nine taps) or 1..8");
+    for (int k = 0; k < d->conv_ntap; ++k)
+      if (((d->conv_taps >> (4 * k)) & 15u) > 8u) HI3D_FAIL(HI3D_EINVAL, "conv3x3: conv_taps holds a tap index > 8");
+    if (d->conv_ntap && (d->up2x || d->stride != 1)) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: a tap subset needs stride 1 and no up2x");
+    if (d->Cin <= 0 || d->Cin % 64 || d->K != ntap * d->Cin) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: need Cin % 64 == 0 and K == 9*Cin (conv_ntap*Cin with a tap subset)");
     if (d->Hin <= 0 || d->Win <= 0 || d->Hout <= 0 || d->Wout <= 0) HI3D_FAIL(HI3D_EINVAL, "conv3x3: bad geometry");
     if (d->stride != 1 && d->stride != 2) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: stride must be 1 or 2");
     if (d->up2x && d->stride != 1) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: up2x needs stride 1");
@@ -1067,7 +1077,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     int dev = -1;
     static const int force = [] { const char* e = getenv("HI3D_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
     if (force != 0 && hipGetDevice(&dev) == hipSuccess && (ws = ws_for(dev, (hipStream_t)stream, g_capture == nullptr)) != nullptr) {
-      const int taps = d->amode == HI3D_A_CONV3X3 ? 9 : d->amode == HI3D_A_CONVT3 ? 3 : 1;
+      const int taps = d->amode == HI3D_A_CONV3X3 ? p.ntap : d->amode == HI3D_A_CONVT3 ? 3 : 1;
       const int units = d->K / BK / taps;
       const long part = (long)d->M * d->N * 4, tiles = (long)((d->M + 127) / 128) * ((d->N + tile - 1) / tile);
       ksplit = splitk_choose(tiles, units, taps, part, ws->bytes);

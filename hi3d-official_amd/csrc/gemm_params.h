@@ -23,6 +23,8 @@ struct GemmParams {
   // A2 (pitch lda2) -- the decoder's skip concat `th.cat([h, hs.pop()], dim=1)` (video_model.py:490-499) as two K segments
   // of the 1x1 skip_connection GEMM instead of a materialised [M, C1 + C2] tensor
   const char* A2; int lda2, K1;
+  int ntap;    // conv3x3: K slabs per 64-channel block -- 9, or the length of a tap SUBSET (`taps`: 4-bit tap indices ky*3+kx,
+  unsigned taps;   // first in the low nibble; W then holds [N][ntap][Cin]) -- the 2x2 phase filters of an up-sampling conv
   long wgs;    // per-row-group weight matrices: elements between the W of consecutive groups of rpg rows (0 = one shared W)
   // GroupNorm statistics of the OUTPUT, emitted by the producer (wide ping-pong tile, affine epilogue without residual / blend
   // terms; the host checks the geometry): per 64-row block of the output and per group of N / 32 channels the (sum, sum of

@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("Wout", C.c_int32), ("stride", C.c_int32), ("up2x", C.c_int32),
         ("T", C.c_int32), ("HW", C.c_int32), ("tile_n", C.c_int32), ("pad_br_only", C.c_int32),
         ("A2", C.c_void_p), ("K1", C.c_int32), ("lda2", C.c_int32), ("gn_partial", C.c_void_p), ("w_group_stride", C.c_int64),
+        ("conv_ntap", C.c_int32), ("conv_taps", C.c_uint32),
     ]
 
 

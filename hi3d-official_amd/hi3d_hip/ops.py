@@ -106,6 +106,10 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
         for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "up2x"):
             setattr(d, k, int(conv3x3[k]))
         d.pad_br_only = int(conv3x3.get("pad_br_only", 0))
+        taps = conv3x3.get("taps")                   # a tap subset (ky*3 + kx each): K = len(taps) * Cin
+        if taps:
+            d.conv_ntap = len(taps)
+            d.conv_taps = sum(int(t) << (4 * k) for k, t in enumerate(taps))
     elif convt3 is not None:
         d.amode = _l.A_CONVT3
         d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])

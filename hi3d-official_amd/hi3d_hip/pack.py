@@ -30,6 +30,30 @@ def pack_conv3x3(w, cin_pad=None, cout_pad=None):
     return out.reshape(Op, 9 * Ip).contiguous()
 
 
+def pack_conv3x3_up_phases(w):
+    """Upsample(2x nearest) + conv3x3 pad 1 (openaimodel.py:107-146) as four 2x2 convolutions on the LOW-resolution image, one
+    per output phase (a, b) = (y & 1, x & 1): output pixel (2i + a, 2j + b) reads up-sampled rows 2i + a + ky - 1, i.e. source
+    rows i - 1 (ky = 0), i, i (a = 0) or i, i, i + 1 (a = 1) -- two source rows, the weights of the coinciding taps summed
+    (fp32, then bf16); columns alike.  In terms of the 3x3 pad-1 gather on the source image the phase reads taps
+    (a + dy, b + dx), dy, dx in {0, 1}.  Returns [(W_ab [O, 4 * I] bf16 laid out [O][dy*2+dx][I], taps (ky*3+kx) x 4)] for
+    (a, b) = (0,0), (0,1), (1,0), (1,1): 4/9 of the multiply-adds of the 3x3 conv on the up-sampled image."""
+    O, I = w.shape[:2]
+    wf = w.detach().float()
+    sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # phase -> original taps merged into (d = 0, d = 1)
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            m = torch.zeros((O, 2, 2, I), dtype=torch.float32, device=w.device)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    for ky in sets[a][dy]:
+                        for kx in sets[b][dx]:
+                            m[:, dy, dx, :] += wf[:, :, ky, kx]
+            taps = tuple((a + dy) * 3 + (b + dx) for dy in (0, 1) for dx in (0, 1))
+            out.append((m.reshape(O, 4 * I).to(torch.bfloat16).contiguous(), taps))
+    return out
+
+
 def pack_convt3(w):
     """Conv3d (3,1,1) weight [O, I, 3, 1, 1] -> [O, (kt, I)]."""
     O, I = w.shape[:2]

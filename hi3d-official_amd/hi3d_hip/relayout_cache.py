@@ -22,7 +22,7 @@ import os
 
 import torch
 
-PACK_VERSION = 3   # 3: to_q rows of spatial blocks carry softmax scale * log2(e)
+PACK_VERSION = 4   # 3: to_q rows of spatial blocks carry softmax scale * log2(e); 4: + the 2x2 phase filters of the up-sampling convs
 
 
 def fingerprint(state_dict, cfg, prefix=""):

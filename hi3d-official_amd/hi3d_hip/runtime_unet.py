@@ -92,6 +92,7 @@ class UNetRuntime:
         # stage 1 at 512^2 loses 0.4 of 45.1 ms: its half-batch launches under-fill the chip); 1 = always, 0 = never
         self.two_stream = os.environ.get("HI3D_TWO_STREAM", "auto")
         self.two_stream_lag = int(os.environ.get("HI3D_TWO_STREAM_LAG", "0"))
+        self.up_phases = os.environ.get("HI3D_UP_PHASES", "1") != "0"
         self._side, self._plan = None, None
         self.last_forward_two_stream = False
         self._clip = {}         # (F, T) -> clip-constant buffers, see clip_consts()
@@ -188,6 +189,8 @@ class UNetRuntime:
                     W[p + ".w"] = pack.pack_conv3x3(g(p + ".op.weight")); W[p + ".b"] = f32(p + ".op.bias")
                 elif L[0] == "up":
                     W[p + ".w"] = pack.pack_conv3x3(g(p + ".conv.weight")); W[p + ".b"] = f32(p + ".conv.bias")
+                    for ph, (wp, _) in enumerate(pack.pack_conv3x3_up_phases(g(p + ".conv.weight"))):
+                        W[f"{p}.w.ph{ph}"] = wp          # (HI3D_UP_PHASES: four 2x2 filters on the low-resolution image)
         W["out.0.g"] = f32("out.0.weight"); W["out.0.b"] = f32("out.0.bias")
         W["out.2.w"] = pack.pack_conv3x3(g("out.2.weight")); W["out.2.b"] = f32("out.2.bias")
         W["emb_all.w"] = torch.cat(emb_w, 0).contiguous(); W["emb_all.b"] = torch.cat(emb_b, 0).contiguous()
@@ -462,8 +465,21 @@ class UNetRuntime:
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=Ho, Wout=Wo, stride=2, up2x=0))
                     cur["H"], cur["W"] = Ho, Wo
                 elif L[0] == "up":
-                    h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
-                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
+                    if self.up_phases:
+                        # Upsample (nearest 2x) + conv3x3 (openaimodel.py:107-146) = four 2x2 convolutions on the low-resolution
+                        # image, one per output phase (y & 1, x & 1), with summed weights (pack.pack_conv3x3_up_phases): 4/9 of
+                        # the multiply-adds; the four phase images [a][b][(f i)][j] are then interleaved to [(f i)][a][j][b]
+                        Ml, Cc = F_c * Hc * Wc, L[1]
+                        tmp = torch.empty((4, Ml, Cc), device=h.device, dtype=torch.bfloat16)
+                        for ph in range(4):
+                            a_, b_ = ph >> 1, ph & 1
+                            taps = tuple((a_ + dy) * 3 + (b_ + dx) for dy in (0, 1) for dx in (0, 1))
+                            ops.gemm(h, W[f"{p}.w.ph{ph}"], M=Ml, N=Cc, K=4 * Cc, bias=W[p + ".b"], out=tmp[ph],
+                                     conv3x3=dict(Hin=Hc, Win=Wc, Cin=Cc, Hout=Hc, Wout=Wc, stride=1, up2x=0, taps=taps))
+                        h = ops.permute_rows(tmp, (2, 2, F_c * Hc, Wc), (2, 0, 3, 1)).reshape(4 * Ml, Cc)
+                    else:
+                        h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
+                                     conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
                     cur["H"], cur["W"] = 2 * Hc, 2 * Wc
                 if L[0] in ("res", "attn") and getattr(c, "after_layer", None) is not None:
                     c.after_layer()                  # (two-stream lag: the other half may be started here)

@@ -121,6 +121,12 @@ typedef struct hi3d_gemm_desc {
    * weights and bias (hi3d_groupnorm_fold_linear) -- the normalised tensor is then never written.  rows_per_group must be a
    * multiple of the tile height (256) and divide M. */
   int64_t w_group_stride;
+  /* HI3D_A_CONV3X3 over a SUBSET of the nine taps (round 4; conv_ntap = 0: all nine): K = conv_ntap * Cin, W = [N][conv_ntap][Cin],
+   * K slab k of a channel block reads image tap (conv_taps >> 4k) & 15 = ky*3 + kx.  Upsample(2x nearest) + conv3x3
+   * (openaimodel.py:107-146) is four 2x2 convolutions on the low-resolution image, one per output phase (y & 1, x & 1), whose
+   * weights are sums of the 3x3 weights: 4/9 of the multiply-adds (hi3d_hip/pack.py:pack_conv3x3_up_phases). stride 1, no up2x. */
+  int32_t conv_ntap;
+  uint32_t conv_taps;
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);

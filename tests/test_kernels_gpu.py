@@ -301,6 +301,38 @@ def test_ffn_geglu_race_screen(dev, blend, monkeypatch):
     assert relerr(first, other.float()) < 4e-3
 
 
+@pytest.mark.parametrize("Fr,H,W_,C", [(2, 16, 16, 128), (3, 8, 24, 64), (1, 32, 32, 320)])
+def test_upsample_conv_as_four_phase_convs(dev, Fr, H, W_, C):
+    """Round 4: Upsample(nearest 2x) + conv3x3 (openaimodel.py:107-146) computed as four 2x2 convolutions on the low-resolution
+    image -- a tap SUBSET of the 3x3 gather (hi3d_gemm_desc.conv_ntap / conv_taps) with the coinciding taps' weights summed
+    (pack.pack_conv3x3_up_phases) -- and interleaved: 4/9 of the multiply-adds.  Against fp32 torch on the up-sampled image and
+    against the up2x gather of the nine-tap kernel (sums of bf16 weights are rounded once more: rounding noise, not bits)."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3, pack_conv3x3_up_phases
+    x = bf(rnd((Fr, C, H, W_), 401))
+    w = bf(rnd((C, C, 3, 3), 402, (9 * C) ** -0.5)).float()
+    b = rnd((C,), 403)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w, b, padding=1)       # [Fr, C, 2H, 2W]
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, C).to(dev)
+    Ml = Fr * H * W_
+    tmp = torch.empty((4, Ml, C), device=dev, dtype=torch.bfloat16)
+    for ph, (wp, taps) in enumerate(pack_conv3x3_up_phases(w)):
+        a_, b_ = ph >> 1, ph & 1
+        assert taps == tuple((a_ + dy) * 3 + (b_ + dx) for dy in (0, 1) for dx in (0, 1))
+        ops.gemm(xt, wp.to(dev), M=Ml, N=C, K=4 * C, bias=b.to(dev), out=tmp[ph],
+                 conv3x3=dict(Hin=H, Win=W_, Cin=C, Hout=H, Wout=W_, stride=1, up2x=0, taps=taps))
+    out = ops.permute_rows(tmp, (2, 2, Fr * H, W_), (2, 0, 3, 1)).reshape(Fr, 2 * H, 2 * W_, C)
+    out = out.permute(0, 3, 1, 2).float().cpu()
+    nine = ops.gemm(xt, pack_conv3x3(w, C).to(dev), M=4 * Ml, N=C, K=9 * C, bias=b.to(dev),
+                    conv3x3=dict(Hin=H, Win=W_, Cin=C, Hout=2 * H, Wout=2 * W_, stride=1, up2x=1))
+    nine = nine.reshape(Fr, 2 * H, 2 * W_, C).permute(0, 3, 1, 2).float().cpu()
+    print(f"up-conv as four phase convs: rel vs fp32 {relerr(out, ref):.2e}, vs the nine-tap up2x gather {relerr(out, nine):.2e}")
+    assert relerr(out, ref) < BF16_TOL and relerr(out, nine) < 8e-3
+    with pytest.raises(ops._l.Hi3dError):               # a tap subset is a stride-1, same-size gather
+        ops.gemm(xt, pack_conv3x3_up_phases(w)[0][0].to(dev), M=4 * Ml, N=C, K=4 * C,
+                 conv3x3=dict(Hin=H, Win=W_, Cin=C, Hout=2 * H, Wout=2 * W_, stride=1, up2x=1, taps=(0, 1, 3, 4)))
+
+
 @pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
                                                          (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
                                                          (2, 9, 9, 64, 64, 2, 0)])
