@@ -50,6 +50,7 @@ VAE_FLASH = os.environ.get("HI3D_VAE_FLASH", "0") == "1"
 # MFMA-bound convolutions of the other and the tails of one frame's short launches are filled by the other's.  Each stream has
 # its own split-K / GroupNorm scratch (ops keys them by stream); results are the same launches on the same data.
 VAE_STREAMS = int(os.environ.get("HI3D_VAE_STREAMS", "2"))
+UP_PHASES = os.environ.get("HI3D_UP_PHASES", "1") != "0"   # up-sampling convs as four 2x2 phase convs (see VAEDecoderRuntime._conv)
 _SIDE = {}
 
 
@@ -127,6 +128,8 @@ class VAEDecoderRuntime:
             if lvl != 0:
                 W[f"up.{lvl}.up.w"] = pack.pack_conv3x3(g(f"{D}up.{lvl}.upsample.conv.weight"))
                 W[f"up.{lvl}.up.b"] = f32(f"{D}up.{lvl}.upsample.conv.bias")
+                for ph, (wp, _) in enumerate(pack.pack_conv3x3_up_phases(g(f"{D}up.{lvl}.upsample.conv.weight"))):
+                    W[f"up.{lvl}.up.w.ph{ph}"] = wp      # (HI3D_UP_PHASES: four 2x2 filters on the low-resolution image)
         W["norm_out.g"] = f32(D + "norm_out.weight"); W["norm_out.b"] = f32(D + "norm_out.bias")
         self.out_ch = self.dd["out_ch"]
         ocp = (self.out_ch + 3) // 4 * 4
@@ -136,6 +139,17 @@ class VAEDecoderRuntime:
 
     # ------------------------------------------------------------------
     def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False, gn=None):
+        if up and UP_PHASES and (key + ".w.ph0") in self.W and R1 is None and not out_fp32 and gn is None:
+            # Upsample (nearest 2x) + conv3x3 (model.py:67-71) as four 2x2 convolutions on the low-resolution image, one per
+            # output phase, with summed weights (pack.pack_conv3x3_up_phases): 4/9 of the multiply-adds, then one row interleave
+            Ml = N * H * Wd
+            tmp = torch.empty((4, Ml, Cout), device=x.device, dtype=torch.bfloat16)
+            for ph in range(4):
+                a_, b_ = ph >> 1, ph & 1
+                taps = tuple((a_ + dy) * 3 + (b_ + dx) for dy in (0, 1) for dx in (0, 1))
+                ops.gemm(x, self.W[f"{key}.w.ph{ph}"], M=Ml, N=Cout, K=4 * Cin, bias=self.W[key + ".b"], out=tmp[ph],
+                         conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0, taps=taps))
+            return ops.permute_rows(tmp, (2, 2, N * H, Wd), (2, 0, 3, 1)).reshape(4 * Ml, Cout)
         Ho, Wo = (2 * H, 2 * Wd) if up else (H, Wd)
         return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
                         out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up), gn=gn)
