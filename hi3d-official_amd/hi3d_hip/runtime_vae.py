@@ -66,10 +66,16 @@ def run_chunks(fn, chunks, device):
         pool = _SIDE.setdefault(dev.index, [])
         while len(pool) < n - 1:
             pool.append(torch.cuda.Stream(device=dev))
+        # Chunk 0 is ISSUED on the caller's stream before the side streams are let go: whatever the first call builds lazily on
+        # that stream (the model's HIP runtime re-lays its weights out on first use) must be complete before another stream
+        # reads it -- the side streams therefore start behind chunk 0 and run next to chunks 2, 3, ...  (Found as NaN frames in
+        # a decode that was the model's first, in a long pytest process: the side stream read weights still being packed.)
+        outs = [fn(*chunks[0])]
         for side in pool[:n - 1]:
-            side.wait_stream(main)                               # the latents were produced on the caller's stream
-        outs = []
+            side.wait_stream(main)                               # (also: the latents were produced on the caller's stream)
         for i, (lo, hi) in enumerate(chunks):
+            if i == 0:
+                continue
             if i % n == 0:
                 outs.append(fn(lo, hi))
             else:

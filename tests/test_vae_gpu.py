@@ -70,6 +70,15 @@ def test_chunks_on_two_streams_equal_one_stream(dev, monkeypatch):
             for _ in range(2):
                 out = eng.decode_first_stage(z)
                 assert torch.equal(out, ref), (name, ns)
+        # a model whose FIRST call goes through the two-stream loop: its runtime (weight re-layout) is built inside chunk 0, on the
+        # caller's stream -- the side stream must not start before that is complete (round 4: NaN frames otherwise)
+        for rep in range(3):
+            junk = torch.full((64 << 20,), float("nan"), device=dev)        # (poison what the allocator hands out next)
+            del junk
+            fresh = AutoencoderKL(embed_dim=4, ddconfig=fx["ddconfig"])
+            synth.fill_module_(fresh, fx["weight_seed"], prefix=fx["key_prefix"])
+            eng.first_stage_model = fresh.to(dev)
+            assert torch.equal(eng.decode_first_stage(z), ref), (name, "first call", rep)
         if name == "vae_tiny":                                  # the encoder's chunk loop (posterior .sample(): same noise order)
             x = ref.clamp(-1, 1)
             monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
