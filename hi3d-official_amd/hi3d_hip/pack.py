@@ -38,19 +38,25 @@ def pack_conv3x3_up_phases(w):
     (a + dy, b + dx), dy, dx in {0, 1}.  Returns [(W_ab [O, 4 * I] bf16 laid out [O][dy*2+dx][I], taps (ky*3+kx) x 4)] for
     (a, b) = (0,0), (0,1), (1,0), (1,1): 4/9 of the multiply-adds of the 3x3 conv on the up-sampled image."""
     O, I = w.shape[:2]
-    wf = w.detach().float()
+    return [(m.reshape(O, 4 * I).to(torch.bfloat16).contiguous(), taps) for m, taps in up_phase_filters(w)]
+
+
+def up_phase_filters(w):
+    """The arithmetic of pack_conv3x3_up_phases in the weights' own precision: [(m [O, 2, 2, I] (dy, dx), taps)] per phase
+    (a, b) = (0,0), (0,1), (1,0), (1,1) (tests/test_host_cpu.py checks it against conv2d on the up-sampled image)."""
+    O, I = w.shape[:2]
+    wf = w.detach() if w.dtype == torch.float64 else w.detach().float()
     sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}          # phase -> original taps merged into (d = 0, d = 1)
     out = []
     for a in (0, 1):
         for b in (0, 1):
-            m = torch.zeros((O, 2, 2, I), dtype=torch.float32, device=w.device)
+            m = torch.zeros((O, 2, 2, I), dtype=wf.dtype, device=w.device)
             for dy in (0, 1):
                 for dx in (0, 1):
                     for ky in sets[a][dy]:
                         for kx in sets[b][dx]:
                             m[:, dy, dx, :] += wf[:, :, ky, kx]
-            taps = tuple((a + dy) * 3 + (b + dx) for dy in (0, 1) for dx in (0, 1))
-            out.append((m.reshape(O, 4 * I).to(torch.bfloat16).contiguous(), taps))
+            out.append((m, tuple((a + dy) * 3 + (b + dx) for dy in (0, 1) for dx in (0, 1))))
     return out
 
 

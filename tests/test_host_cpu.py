@@ -593,3 +593,24 @@ def test_reference_yaml_loads_verbatim(name, tmp_path):
     assert any(k.startswith("model.diffusion_model.input_blocks.0.0.weight") for k in keys)
     assert any(k.startswith("first_stage_model.decoder.conv_in.weight") for k in keys)
     assert len(m.conditioner.embedders) == len(y0["model"]["params"]["conditioner_config"]["params"]["emb_models"])
+
+
+def test_upsample_conv_phase_filters_are_the_upsampled_conv():
+    """Round 4: Upsample(nearest 2x) + conv3x3 pad 1 (openaimodel.py:107-146) == four 2x2 filters on the low-resolution image,
+    one per output phase (pack.up_phase_filters): exact algebra, checked in fp64 against conv2d on the up-sampled image -- the
+    tap subset (ky*3 + kx of the 3x3 pad-1 gather) each phase names is what the HIP gather reads (hi3d_gemm_desc.conv_taps)."""
+    import torch.nn.functional as F
+    from hi3d_hip.pack import up_phase_filters
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 6, 5, 7), generator=g, dtype=torch.float64)
+    w = torch.randn((4, 6, 3, 3), generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)            # [2, 4, 10, 14]
+    xp = F.pad(x, (1, 1, 1, 1))                                                               # the 3x3 pad-1 gather's view
+    for ph, (m, taps) in enumerate(up_phase_filters(w)):
+        a, b = ph >> 1, ph & 1
+        assert taps == tuple((a + dy) * 3 + (b + dx) for dy in (0, 1) for dx in (0, 1))
+        out = torch.zeros((2, 4, 5, 7), dtype=torch.float64)
+        for q, t in enumerate(taps):                      # tap t = ky*3 + kx reads source pixel (i + ky - 1, j + kx - 1)
+            ky, kx = divmod(t, 3)
+            out += torch.einsum("nchw,oc->nohw", xp[:, :, ky:ky + 5, kx:kx + 7], m[:, q // 2, q % 2, :])
+        assert torch.allclose(out, ref[:, :, a::2, b::2], atol=1e-12), ph
