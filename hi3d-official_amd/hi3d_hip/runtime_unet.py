@@ -469,14 +469,7 @@ class UNetRuntime:
                         # Upsample (nearest 2x) + conv3x3 (openaimodel.py:107-146) = four 2x2 convolutions on the low-resolution
                         # image, one per output phase (y & 1, x & 1), with summed weights (pack.pack_conv3x3_up_phases): 4/9 of
                         # the multiply-adds; the four phase images [a][b][(f i)][j] are then interleaved to [(f i)][a][j][b]
-                        Ml, Cc = F_c * Hc * Wc, L[1]
-                        tmp = torch.empty((4, Ml, Cc), device=h.device, dtype=torch.bfloat16)
-                        for ph in range(4):
-                            a_, b_ = ph >> 1, ph & 1
-                            taps = tuple((a_ + dy) * 3 + (b_ + dx) for dy in (0, 1) for dx in (0, 1))
-                            ops.gemm(h, W[f"{p}.w.ph{ph}"], M=Ml, N=Cc, K=4 * Cc, bias=W[p + ".b"], out=tmp[ph],
-                                     conv3x3=dict(Hin=Hc, Win=Wc, Cin=Cc, Hout=Hc, Wout=Wc, stride=1, up2x=0, taps=taps))
-                        h = ops.permute_rows(tmp, (2, 2, F_c * Hc, Wc), (2, 0, 3, 1)).reshape(4 * Ml, Cc)
+                        h = ops.upsample_conv_phases(h, [W[f"{p}.w.ph{ph}"] for ph in range(4)], W[p + ".b"], F_c, Hc, Wc, L[1])
                     else:
                         h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
                                      conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))

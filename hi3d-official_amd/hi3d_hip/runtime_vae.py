@@ -145,17 +145,10 @@ class VAEDecoderRuntime:
 
     # ------------------------------------------------------------------
     def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False, gn=None):
-        if up and UP_PHASES and (key + ".w.ph0") in self.W and R1 is None and not out_fp32 and gn is None:
+        if up and UP_PHASES and (key + ".w.ph0") in self.W and R1 is None and not out_fp32 and gn is None and Cin == Cout:
             # Upsample (nearest 2x) + conv3x3 (model.py:67-71) as four 2x2 convolutions on the low-resolution image, one per
             # output phase, with summed weights (pack.pack_conv3x3_up_phases): 4/9 of the multiply-adds, then one row interleave
-            Ml = N * H * Wd
-            tmp = torch.empty((4, Ml, Cout), device=x.device, dtype=torch.bfloat16)
-            for ph in range(4):
-                a_, b_ = ph >> 1, ph & 1
-                taps = tuple((a_ + dy) * 3 + (b_ + dx) for dy in (0, 1) for dx in (0, 1))
-                ops.gemm(x, self.W[f"{key}.w.ph{ph}"], M=Ml, N=Cout, K=4 * Cin, bias=self.W[key + ".b"], out=tmp[ph],
-                         conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0, taps=taps))
-            return ops.permute_rows(tmp, (2, 2, N * H, Wd), (2, 0, 3, 1)).reshape(4 * Ml, Cout)
+            return ops.upsample_conv_phases(x, [self.W[f"{key}.w.ph{ph}"] for ph in range(4)], self.W[key + ".b"], N, H, Wd, Cout)
         Ho, Wo = (2 * H, 2 * Wd) if up else (H, Wd)
         return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
                         out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up), gn=gn)
