@@ -411,6 +411,26 @@ def groupnorm_silu_sharded(x, gamma, beta, inst, P, C, eps, allreduce_, world, s
 # 199.12 ms: those passes already ran under the other CFG half's matrix-core kernels) -- profiles/r04s_gn_fold_ab.log
 GN_FOLD = os.environ.get("HI3D_GN_FOLD", "0") == "1"
 
+
+def groupnorm_fold_linear(x, gamma, beta, inst, P, C, eps, W, bias, N):
+    """The statistics of GroupNorm(32; no activation) over x [inst * P, C] folded into the linear layer (W [N, C] bf16 K-major,
+    bias [N] fp32 or None) that consumes the normalised tensor: returns (Wf [inst, N, C] bf16, biasf [inst, N] fp32) for
+    gemm(x, Wf, ..., rowvec=biasf, rows_per_group=P, w_group_stride=N * C).  See include/hi3d_hip.h.
+    Reference: SpatialTransformer.norm + proj_in, sgm/modules/attention.py:702-712."""
+    _chk_dev(x, gamma, beta, W, bias)
+    assert W.dtype == torch.bfloat16 and W.is_contiguous() and W.shape[-1] == C and W.shape[0] == N
+    ws = _gn_workspace(x.device, inst, P, C)
+    Wf = torch.empty((inst, N, C), device=x.device, dtype=torch.bfloat16)
+    biasf = torch.empty((inst, N), device=x.device, dtype=torch.float32)
+    prof = PROFILER
+    t0 = prof.begin() if prof else None
+    _l.check(_lib.hi3d_groupnorm_fold_linear(_p(x), _p(ws), _p(gamma), _p(beta), float(eps), inst, P, C, _p(W), C, _p(bias), N,
+                                             _p(Wf), _p(biasf), _stream()), "hi3d_groupnorm_fold_linear")
+    if prof:
+        prof.end("groupnorm_silu", 0.0, 2.0 * inst * P * C, t0)
+    return Wf, biasf
+
+
 def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C):
     """Upsample(nearest 2x) + conv3x3 pad 1 on x [frames * H * Wd, C] (channels-last rows) -> [frames * 2H * 2Wd, C] as four 2x2
     phase convolutions on the low-resolution image (pack.pack_conv3x3_up_phases: w_phases[a * 2 + b] = [C, 4 * C]): the phases are

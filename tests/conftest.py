@@ -10,6 +10,74 @@ for p in (PKG, ROOT):
         sys.path.insert(0, p)
 
 
+# Which GPU tests are the evidence for which row of SURVEY.md 8 (the grading contract).  `pytest -m gpu -x` stops at the first
+# failure, so the ORDER decides what a single broken test can hide: round 4 ended with an opt-in experiment's kernel test
+# (alphabetically early) in front of every VideoDecoder / checkpoint / torch.ops / clip-parallel test, and 150 tests never ran.
+# pytest_collection_modifyitems below runs (0) the row evidence in this order, (1) the remaining kernel / property tests,
+# (2) stress screens, 1000-launch repeatability runs and tests of opt-in (default-off) code paths -- last.
+# A node id matches an entry when the entry is a substring of it.  tests/test_host_cpu.py checks that every row has a test.
+ROW_TESTS = [
+    ("a1-a6 sampler step / guider / denoiser / wrapper", [
+        "test_unet_gpu.py::test_sampler_matches_reference_golden",
+        "test_at_size_gpu.py::test_sampler_25_steps_full_width_matches_reference_golden",
+        "test_unet_gpu.py::test_fused_graph_step_equals_generic_step",
+        "test_kernels_gpu.py::test_cfg_prepare_and_sampler_step",
+        "test_unet_gpu.py::test_guidance_scale_change_after_graph_capture_takes_effect"]),
+    ("a7-a15 VideoUNet.forward and its blocks", [
+        "test_unet_gpu.py::test_unet_matches_reference_golden",
+        "test_unet_gpu.py::test_unet_full_size_stage1_matches_reference_golden",
+        "test_at_size_gpu.py::test_unet_full_size_stage2_matches_reference_golden[bf16]",
+        "test_at_size_gpu.py::test_unet_full_width_32_views_matches_reference_golden",
+        "test_unet_gpu.py::test_unet_vs_oracle_other_shape",
+        "test_unet_gpu.py::test_unet_32_views_vs_oracle"]),
+    ("a16 decode_first_stage / Decoder", [
+        "test_vae_gpu.py::test_vae_decode_matches_reference_golden",
+        "test_at_size_gpu.py::test_vae_decode_full_resolution_matches_reference_golden",
+        "test_vae_gpu.py::test_engine_decode_first_stage_chunks"]),
+    ("a17 encode_first_stage / Encoder / posterior", [
+        "test_vae_gpu.py::test_vae_encode_matches_reference_golden",
+        "test_at_size_gpu.py::test_vae_encode_full_resolution_matches_reference_golden",
+        "test_vae_gpu.py::test_autoencoding_engine_encode_matches_reference_golden",
+        "test_vae_gpu.py::test_cond_frame_embedder_matches_reference_encoder"]),
+    ("a18 v02 blend loop", [
+        "test_unet_gpu.py::test_stage2_refine_loop_matches_reference_golden",
+        "test_at_size_gpu.py::test_stage2_refine_25_steps_full_width_matches_reference_golden"]),
+    ("a20 / f1 VideoDecoder, AE3DConv", ["test_vae_gpu.py::test_video_decoder"]),
+    ("b boundary: torch.ops.hi3d, error convention", ["test_torch_ops_gpu.py::", "test_kernels_gpu.py::test_errors_are_loud"]),
+    ("e multi-GPU: CFG split, frame<->space all-to-all, sharded decode", ["test_parallel_gpu.py::"]),
+    ("f2 VAE encoder + v02 pre-loop, clips end to end", [
+        "test_depth_gpu.py::test_v02_conditioner_end_to_end", "test_pipeline_gpu.py::test_stage2_clip_from_yaml",
+        "test_pipeline_gpu.py::test_stage1_clip_create_model_sample_decode"]),
+    ("f3 conditioner on the GPU", [
+        "test_clip_gpu.py::test_openclip_prediction_embedder_end_to_end", "test_clip_gpu.py::test_aes_embedder_end_to_end",
+        "test_clip_gpu.py::test_vit_runtime", "test_depth_gpu.py::test_depth_embedder", "test_depth_gpu.py::test_dpt_hybrid_matches_reference_midas"]),
+    ("f4 checkpoint loader, re-layout cache", [
+        "test_pipeline_gpu.py::test_deepspeed_checkpoint_to_runtime_matches_reference_golden",
+        "test_pipeline_gpu.py::test_pack_cache_cold_and_warm_are_bit_identical"]),
+    ("N1 fp8 attention (BASELINE config 5)", [
+        "test_at_size_gpu.py::test_unet_full_size_stage2_matches_reference_golden[fp8",
+        "test_at_size_gpu.py::test_sampler_25_steps_full_width_fp8_attention", "test_unet_gpu.py::test_unet_fp8_attention_paths"]),
+]
+# run last: timing-stress / race screens / long repeatability runs, and tests of code paths that are OFF by default
+LAST_TESTS = ["isa_timing_stress", "race_screen", "ragged_repeatable", "test_groupnorm_folded_into_the_linear_layer",
+              "test_attention_d512", "test_gemm_split_k_scratch_is_per_stream"]
+
+
+def row_priority(nodeid):
+    """(class, index): class 0 = evidence of a SURVEY 8 row (index = position in ROW_TESTS), 1 = everything else, 2 = LAST_TESTS."""
+    for i, (_, pats) in enumerate(ROW_TESTS):
+        if any(p in nodeid for p in pats):
+            return (0, i)
+    if any(p in nodeid for p in LAST_TESTS):
+        return (2, 0)
+    return (1, 0)
+
+
+def pytest_collection_modifyitems(config, items):
+    order = {id(it): n for n, it in enumerate(items)}
+    items.sort(key=lambda it: row_priority(it.nodeid) + (order[id(it)],))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -614,3 +614,69 @@ def test_upsample_conv_phase_filters_are_the_upsampled_conv():
             ky, kx = divmod(t, 3)
             out += torch.einsum("nchw,oc->nohw", xp[:, :, ky:ky + 5, kx:kx + 7], m[:, q // 2, q % 2, :])
         assert torch.allclose(out, ref[:, :, a::2, b::2], atol=1e-12), ph
+
+
+def test_gemm_dispatch_of_the_headline_shapes_needs_no_gpu():
+    """hi3d_debug_gemm_launch_info describes the launch hi3d_gemm_bf16 WOULD make (kernel instantiation, grid, LDS) without making
+    it -- so the host-side tile choice for the benchmarked shapes (variant 7 = 256 x 320 ping-pong for QKV / conv
+    gathers / long-K dense, the 128 x 32 tile for the 4-channel output conv) is pinned here, on a box without a GPU."""
+    import ctypes as C
+    from hi3d_hip import lib as L
+    lib = L.load()
+    buf, info = (C.c_char * 512)(), (C.c_int32 * 10)()
+
+    def describe(M, N, K, **kw):
+        d = L.GemmDesc()
+        d.A = d.W = d.out = 4096
+        d.M, d.N, d.K, d.lda, d.ldo, d.ldw, d.rows_per_group = M, N, K, kw.pop("lda", K), N, K, 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        rc = lib.hi3d_debug_gemm_launch_info(C.byref(d), buf, info)
+        assert rc == 0, lib.hi3d_last_error().decode()
+        size, grid, block, smem, WM, NT, NS, AMODE, EPI, PP = list(info)
+        assert 0 < size <= 512 and smem <= 160 * 1024 and block in (256, 512)
+        return dict(grid=grid, block=block, smem=smem, WM=WM, NT=NT, NS=NS, AMODE=AMODE, EPI=EPI, PP=PP)
+
+    qkv = describe(524288, 960, 320)                                    # QKV at the 128^2 level of the stage-2 step
+    assert (qkv["WM"], qkv["NT"], qkv["PP"], qkv["block"]) == (4, 10, 1, 512) and qkv["grid"] == 2048 * 3
+    conv = describe(524288, 320, 2880, lda=320, amode=L.A_CONV3X3, Hin=128, Win=128, Cin=320, Hout=128, Wout=128, stride=1)
+    assert (conv["AMODE"], conv["PP"], conv["WM"]) == (L.A_CONV3X3, 1, 4)
+    geglu = describe(524288, 2560, 320, epi=L.EPI_GEGLU)
+    assert geglu["EPI"] == L.EPI_GEGLU
+    out4 = describe(524288, 4, 2880, lda=320, amode=L.A_CONV3X3, Hin=128, Win=128, Cin=320, Hout=128, Wout=128, stride=1, out_fp32=1)
+    assert out4["NT"] * 32 <= 64                                          # the narrow tile: N = 4 does not pay for 160 columns
+    # the GroupNorm partial-sum workspace: hi3d_gn_workspace_floats is sized from hi3d_gn_partial_blocks (+ 64 floats of statistics
+    # per instance), and the producer-side partial sums (one block per 64 rows) never exceed it
+    for inst, P, Cc in ((32, 16384, 320), (2, 16 * 16384, 320), (1, 1 << 20, 128), (32, 64, 1280)):
+        nb = lib.hi3d_gn_partial_blocks(P, Cc)
+        assert nb >= (P + 63) // 64 or nb >= 1
+        assert lib.hi3d_gn_workspace_floats(inst, P, Cc) == inst * nb * 64 + inst * 64
+
+
+def test_every_survey_row_has_gpu_evidence_and_runs_before_the_stress_screens():
+    """tests/conftest.py:ROW_TESTS maps each row of SURVEY.md 8 to the GPU tests that are its evidence and orders the collection so
+    that those run first (`pytest -m gpu -x` stops at the first failure: what comes first cannot be hidden).  Every pattern must
+    still name an existing test -- a renamed test would silently drop out of the front group."""
+    import ast
+    import conftest
+    here = os.path.dirname(os.path.abspath(__file__))
+    nodes = []
+    for f in sorted(os.listdir(here)):
+        if f.startswith("test_") and f.endswith("_gpu.py"):
+            for n in ast.parse(open(os.path.join(here, f)).read()).body:
+                if isinstance(n, ast.FunctionDef) and n.name.startswith("test_"):
+                    nodes.append(f"tests/{f}::{n.name}")
+    assert len(nodes) > 100
+    for row, pats in conftest.ROW_TESTS:
+        for p in pats:
+            base = p.split("[")[0]
+            assert any(base in n for n in nodes), f"row '{row}': no GPU test matches {p!r}"
+    for p in conftest.LAST_TESTS:
+        assert any(p in n for n in nodes), f"LAST_TESTS: no GPU test matches {p!r}"
+    pr = conftest.row_priority
+    assert pr("tests/test_vae_gpu.py::test_video_decoder_matches_reference_golden[x]")[0] == 0
+    assert pr("tests/test_kernels_gpu.py::test_groupnorm_folded_into_the_linear_layer")[0] == 2          # the round-4 culprit: last
+    assert pr("tests/test_kernels_gpu.py::test_gemm_geglu[a]")[0] == 1
+    rows = " ".join(r for r, _ in conftest.ROW_TESTS)
+    for tag in ("a1", "a7", "a16", "a17", "a18", "a20", "b ", "e ", "f2", "f3", "f4", "N1"):
+        assert tag in rows, tag
