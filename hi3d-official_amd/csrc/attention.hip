@@ -603,6 +603,137 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(
 #endif
 }
 
+// ---- the same for 16 < T <= 32 (BASELINE config 4: 32 views), round 5.  Still one wave per (clip, pixel, head); the frames are
+// cut into two blocks of 16 on BOTH sides: S^T is 2 x 2 blocks of 16 keys x 16 queries (two v_mfma_f32_16x16x32_bf16 each, K =
+// the 64 channels), the softmax of a query runs over 2 blocks x 4 registers x 4 lanes, and O^T[16 channels][16 queries] sums
+// BOTH key blocks in ONE v_mfma_f32_16x16x32_bf16 whose contraction index k = 8 g + 4 kb + r stands for key 16 kb + 4 g + r:
+// on the B side that is exactly the two packed-P register pairs of a lane (block 0 then block 1), on the A side two transposing
+// LDS reads of the same V image position in the two key blocks' image sets.  Everything else -- operand loads straight from
+// the frame-major tensor, lane-linear V images, 16 consecutive output channels per lane -- is the T <= 16 kernel's layout with
+// a block index added (tests/test_kernels_gpu.py runs both kernels on the same T <= 16 inputs).
+// Rounds 1-4 ran this case on the VALU kernel above: 8.35 ms per 32-view step at 2.8 TB/s against 4.3-5.3 TB/s for this form.
+__global__ __launch_bounds__(256) void attn_temporal_mfma32_kernel(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+    const unsigned short* __restrict__ v, unsigned short* __restrict__ out,
+    int B, int T, int S, int H, int ld, int ldo, float scale_log2) {
+#if __HIP_DEVICE_COMPILE__
+  __shared__ __attribute__((aligned(16))) char sV[4 * 4096];     // two 2 KiB V image sets (key blocks 0 / 1) per wave
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const myV = sV + w * 4096;
+  const int t16 = lane & 15, g = lane >> 4;
+  const unsigned nitem = (unsigned)B * S * H;      // (< 2^31: checked by the host)
+  const unsigned stride = gridDim.x * 4;
+  const int vkey = lane >> 2;                     // V loader: key row (within a block) of this lane, channels (lane & 3) * 16 .. + 15
+  constexpr unsigned INV = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const long frame_pitch = (long)S * ld * 2;                                  // bytes between frames of one pixel
+  // per-lane byte offsets of frame block fb (frames 16 fb + ..): loop-invariant; rows that do not exist (frame >= T) carry an
+  // offset beyond the descriptor's range and read as zeros / are not stored (the host checks 32 frames x S x ld x 2 < 2^31)
+  unsigned off_qk[2], off_v[2], off_o[2];
+#pragma unroll
+  for (int fb = 0; fb < 2; ++fb) {
+    off_qk[fb] = (16 * fb + t16 < T) ? (unsigned)((16 * fb + t16) * frame_pitch + g * 16) : INV;
+    off_v[fb] = (16 * fb + vkey < T) ? (unsigned)((16 * fb + vkey) * frame_pitch + (lane & 3) * 32) : INV;
+    off_o[fb] = (16 * fb + t16 < T) ? (unsigned)((16 * fb + t16) * (long)S * ldo * 2 + g * 32) : INV;
+  }
+  for (unsigned it = blockIdx.x * 4 + w; it < nitem; it += stride) {
+    const unsigned bp = it / (unsigned)H, h = it - bp * H;
+    const unsigned b = bp / (unsigned)S, px = bp - b * S;
+    const long base = (((long)b * T * S + px) * ld + h * 64) * 2;            // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)q + base), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)k + base), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)v + base), 0, 0x7fffffff, 0x00020000);
+    // ---- loads: 12 x 16 bytes per lane, all issued before the first use
+    bf16x8 qf[2][2], kf[2][2];
+    u32x4 vv[2][2];
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[fb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsK, off_qk[fb], ks * 64, 0));
+        qf[fb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsQ, off_qk[fb], ks * 64, 0));
+      }
+    }
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+      vv[fb][0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off_v[fb], 0, 0);       // channels 16 a .. + 7      (a = lane & 3)
+      vv[fb][1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, off_v[fb], 16, 0);      // channels 16 a + 8 .. + 15
+    }
+    // ---- S^T blocks: sc[kb][qb][r] = S^T[key 16 kb + 4 g + r][query 16 qb + t16]
+    f32x4 sc[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][ks], qf[qb][ks], a, 0, 0, 0);
+        sc[kb][qb] = a;
+      }
+    // ---- V images of key block kb at kb * 2048: image j <- channels 16 a + 4 j .. + 3 of key `vkey` (8 bytes) at j * 512 + lane * 8
+    // (the previous item's transposing reads of these addresses were consumed by its MFMAs, whose results its stores waited for)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      *(u32x2*)(myV + kb * 2048 + 0 * 512 + lane * 8) = u32x2{vv[kb][0][0], vv[kb][0][1]};
+      *(u32x2*)(myV + kb * 2048 + 1 * 512 + lane * 8) = u32x2{vv[kb][0][2], vv[kb][0][3]};
+      *(u32x2*)(myV + kb * 2048 + 2 * 512 + lane * 8) = u32x2{vv[kb][1][0], vv[kb][1][1]};
+      *(u32x2*)(myV + kb * 2048 + 3 * 512 + lane * 8) = u32x2{vv[kb][1][2], vv[kb][1][3]};
+    }
+    // ---- softmax of query (qb, t16) over 2 key blocks x 4 registers x the 4 lanes {t16 + 16 g'}; P packed = the B operand
+    bf16x8 pk[2];
+    float inv[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float s8[8], mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s8[kb * 4 + r] = (16 * kb + 4 * g + r < T) ? sc[kb][qb][r] * scale_log2 : -INFINITY;
+          mx = fmaxf(mx, s8[kb * 4 + r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float e[8], l = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(s8[i] - mx); l += e[i]; }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      inv[qb] = __builtin_amdgcn_rcpf(l);
+      union { bf16x8 v; unsigned int u[4]; } p8;
+      p8.u[0] = pack_bf16x2(e[0], e[1]); p8.u[1] = pack_bf16x2(e[2], e[3]);       // k = 8 g + 0..3 : keys      4 g + r
+      p8.u[2] = pack_bf16x2(e[4], e[5]); p8.u[3] = pack_bf16x2(e[6], e[7]);       // k = 8 g + 4..7 : keys 16 + 4 g + r
+      pk[qb] = p8.v;
+    }
+    // ---- O^T = V^T P^T: MFMA (j, qb), output row i = 4 g + r  <->  channel 16 g + 4 j + r of query 16 qb + t16
+    float o[2][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      union { bf16x8 v; bf16x4_t h[2]; } vf;
+      vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4_t*)(myV + j * 512 + lane * 8));
+      vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4_t*)(myV + 2048 + j * 512 + lane * 8));
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk[qb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qb][j * 4 + r] = acc[r] * inv[qb];
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)out + (((long)b * T * S + px) * ldo + h * 64) * 2), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(o[qb][0], o[qb][1]), pack_bf16x2(o[qb][2], o[qb][3]),
+                                                   pack_bf16x2(o[qb][4], o[qb][5]), pack_bf16x2(o[qb][6], o[qb][7])}, rsO, off_o[qb], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(o[qb][8], o[qb][9]), pack_bf16x2(o[qb][10], o[qb][11]),
+                                                   pack_bf16x2(o[qb][12], o[qb][13]), pack_bf16x2(o[qb][14], o[qb][15])}, rsO, off_o[qb], 16, 0);
+    }
+  }
+#endif
+}
+
 }  // namespace
 
 namespace {
@@ -691,12 +822,23 @@ extern "C" int hi3d_attn_temporal_d64(const void* q, const void* k, const void* 
   hipStream_t s = (hipStream_t)stream;
   // T <= 16 (every Hi3D clip shape but the 32-view one): the matrix-core kernel, one wave per (clip, pixel, head);
   // HI3D_ATTNT_MFMA=0 selects the round-1..3 VALU kernel (A/B switch)
-  static const int mfma_env = [] { const char* e = getenv("HI3D_ATTNT_MFMA"); return e ? atoi(e) : 1; }();
-  if (mfma_env && T <= 16 && (long)B * S * H < 0x7fffffffL && 16L * S * (ldqkv > ldo ? ldqkv : ldo) * 2 < 0x7fffffffL) {
+  const int mfma_env = [] { const char* e = getenv("HI3D_ATTNT_MFMA"); return e ? atoi(e) : 1; }();   // (read per call: the tests flip it)
+  if (mfma_env && mfma_env != 2 && T <= 16 && (long)B * S * H < 0x7fffffffL && 16L * S * (ldqkv > ldo ? ldqkv : ldo) * 2 < 0x7fffffffL) {
     const long nitem = (long)B * S * H;
     const long want = (nitem + 3) / 4;
     const unsigned grid = (unsigned)(want < 256L * 8 * 4 ? want : 256L * 8 * 4);     // <= 32 blocks of 4 waves per CU's worth
     hipLaunchKernelGGL(attn_temporal_mfma_kernel, dim3(grid), dim3(256), 0, s, (const unsigned short*)q, (const unsigned short*)k,
+                       (const unsigned short*)v, (unsigned short*)out, B, T, S, H, ldqkv, ldo, sl2);
+    HI3D_LAUNCH_CHECK();
+    return HI3D_OK;
+  }
+  // 16 < T <= 32 (the 32-view clip of BASELINE config 4): the two-block form of the same kernel (round 5); HI3D_ATTNT_MFMA=2
+  // sends T <= 16 through it as well (A/B and parity switch: both kernels on the same inputs)
+  if (mfma_env && (T > 16 || mfma_env == 2) && (long)B * S * H < 0x7fffffffL && 32L * S * (ldqkv > ldo ? ldqkv : ldo) * 2 < 0x7fffffffL) {
+    const long nitem = (long)B * S * H;
+    const long want = (nitem + 3) / 4;
+    const unsigned grid = (unsigned)(want < 256L * 8 * 4 ? want : 256L * 8 * 4);
+    hipLaunchKernelGGL(attn_temporal_mfma32_kernel, dim3(grid), dim3(256), 0, s, (const unsigned short*)q, (const unsigned short*)k,
                        (const unsigned short*)v, (unsigned short*)out, B, T, S, H, ldqkv, ldo, sl2);
     HI3D_LAUNCH_CHECK();
     return HI3D_OK;

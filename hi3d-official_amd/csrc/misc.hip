@@ -278,6 +278,37 @@ __global__ void time_mix_small_kernel(const float* __restrict__ x, const float* 
   for (int co = 0; co < C; ++co) out[(f * C + co) * HW + p] = acc[co];
 }
 
+// ... with an isotropic 3 x 3 x 3 kernel (VideoDecoder(video_kernel_size=3), the reference class's default): w [co][ci][kt][ky][kx]
+__global__ void time_mix_small_k3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ b, float* __restrict__ out, int T, int H, int W,
+                                         int C, int ldx, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;    // over (b t) * H * W
+  if (idx >= total) return;
+  const int HW = H * W;
+  const int p = (int)(idx % HW); const long f = idx / HW; const int t = (int)(f % T);
+  const int y = p / W, xx = p - y * W;
+  float acc[4];
+  for (int co = 0; co < C; ++co) acc[co] = b[co];
+  for (int kt = 0; kt < 3; ++kt) {
+    const int tt = t + kt - 1;
+    if (tt < 0 || tt >= T) continue;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      if (yy < 0 || yy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xc = xx + kx - 1;
+        if (xc < 0 || xc >= W) continue;
+        const float* xp = x + ((f + (kt - 1)) * HW + (long)yy * W + xc) * ldx;
+        for (int ci = 0; ci < C; ++ci) {
+          const float v = xp[ci];
+          for (int co = 0; co < C; ++co) acc[co] += w[(((co * C + ci) * 3 + kt) * 3 + ky) * 3 + kx] * v;
+        }
+      }
+    }
+  }
+  for (int co = 0; co < C; ++co) out[(f * C + co) * HW + p] = acc[co];
+}
+
 inline unsigned grid_for(long n, int block, long cap = 65536) {
   long g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -485,6 +516,17 @@ extern "C" int hi3d_time_mix_small(const float* x, const float* w, const float* 
   const long total = (long)B * T * HW;
   hipLaunchKernelGGL(time_mix_small_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
                      x, w, b, out, T, HW, C, ldx, total);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
+extern "C" int hi3d_time_mix_small_k3(const float* x, const float* w, const float* b, float* out, int32_t B,
+                                      int32_t T, int32_t H, int32_t W, int32_t C, int32_t ldx, void* stream) {
+  if (!x || !w || !b || !out) HI3D_FAIL(HI3D_EINVAL, "time_mix_small_k3: null pointer");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 4 || ldx < C) HI3D_FAIL(HI3D_EINVAL, "time_mix_small_k3: bad size");
+  const long total = (long)B * T * H * W;
+  hipLaunchKernelGGL(time_mix_small_k3_kernel, dim3(grid_for(total, 256, 1L << 30)), dim3(256), 0, (hipStream_t)stream,
+                     x, w, b, out, T, H, W, C, ldx, total);
   HI3D_LAUNCH_CHECK();
   return HI3D_OK;
 }

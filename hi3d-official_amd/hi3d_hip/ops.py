@@ -710,6 +710,14 @@ def time_mix_small(x, w, b, B, T, H, W, C):
     return out
 
 
+def time_mix_small_k3(x, w, b, B, T, H, W, C):
+    """x fp32 [(B*T*H*W), ldx] -> fp32 NCHW [B*T, C, H, W]: isotropic Conv3d (3,3,3), padding 1 (w [C, C, 3, 3, 3] fp32)."""
+    assert w.is_contiguous() and tuple(w.shape) == (C, C, 3, 3, 3)
+    out = torch.empty((B * T, C, H, W), device=x.device, dtype=torch.float32)
+    _l.check(_lib.hi3d_time_mix_small_k3(_p(x), _p(w), _p(b), _p(out), B, T, H, W, C, x.stride(0), _stream()), "hi3d_time_mix_small_k3")
+    return out
+
+
 FFN_FUSED_WIDTHS = (320,)   # channel counts hi3d_ffn_geglu is built for
 
 

@@ -308,13 +308,17 @@ class VAEEncoderRuntime(_ResnetMixin):
 
 
 class VideoDecoderRuntime(VAEDecoderRuntime):
-    """Temporal VAE decoder, time_mode 'conv-only' with video_kernel_size [3,1,1]
-    (sgm/modules/autoencoding/temporal_ae.py:18-107,293-349; hooked in by
-    DiffusionEngine.decode_first_stage, models/diffusion.py:126-129).  Every ResnetBlock is
-    followed by a temporal ResBlock (GroupNorm over t,h,w -> SiLU -> Conv3d (3,1,1), twice,
-    no timestep embedding) blended in as x_s + sigmoid(mix_factor) * h_t, and conv_out is
-    followed by a 3-channel Conv3d (3,1,1).  Same kernels as the UNet's time_stack: the frame
-    axis is indexed inside the conv / norm kernels, nothing is permuted."""
+    """Temporal VAE decoder, time_mode 'conv-only' (sgm/modules/autoencoding/temporal_ae.py:18-107,293-349; hooked in by
+    DiffusionEngine.decode_first_stage, models/diffusion.py:126-129).  Every ResnetBlock is followed by a temporal ResBlock
+    (GroupNorm over t,h,w -> SiLU -> Conv3d, twice, no timestep embedding) blended in as x_s + sigmoid(mix_factor) * h_t,
+    and conv_out is followed by a 3-channel Conv3d.  video_kernel_size (read off the weights' shape):
+
+    * [3, 1, 1] (SVD / Hi3D): the UNet's time_stack kernels -- the frame axis is indexed inside the Conv3d (3,1,1) gather and
+      the norm kernels, nothing is permuted;
+    * 3 = [3, 3, 3] (the reference class's default, temporal_ae.py:299): an isotropic Conv3d is the sum over kt of a 2-D 3x3
+      conv of the frame t + kt - 1 -- three launches of the conv3x3 gather on a clip buffer with one zero frame at either end
+      (the GroupNorm writes its output between them), the partial sums carried as the R1 operand of the next launch and the
+      residual / blend tail fused into the last; conv_out's 3-channel time_mix_conv on hi3d_time_mix_small_k3."""
 
     @_on_own_device
     def __init__(self, state_dict, ddconfig, device, prefix=""):
@@ -324,24 +328,60 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
         f32 = lambda k: pack.f32(g(k))
         D = "decoder."
         W = self.W
+        oc = self.out_ch
+        tm = g(D + "conv_out.time_mix_conv.weight")
+        ks = tuple(tm.shape[2:])
+        if ks not in ((3, 1, 1), (3, 3, 3)):
+            raise ops._l.Hi3dError(f"VideoDecoder: video_kernel_size {list(ks)} is not built ([3, 1, 1] and 3 are)")
+        self.iso = ks == (3, 3, 3)
         names = ["mid.block_1", "mid.block_2"] + [f"up.{l}.block.{b}" for l in range(len(self.mult)) for b in range(self.nres + 1)]
         for p in names:
             q = p + ".time_stack"
             for n in ("in_layers.0", "out_layers.0"):
                 W[f"{q}.{n}.g"] = f32(f"{D}{q}.{n}.weight"); W[f"{q}.{n}.b"] = f32(f"{D}{q}.{n}.bias")
             for n in ("in_layers.2", "out_layers.3"):
-                W[f"{q}.{n}.w"] = pack.pack_convt3(g(f"{D}{q}.{n}.weight")); W[f"{q}.{n}.b"] = f32(f"{D}{q}.{n}.bias")
+                w = g(f"{D}{q}.{n}.weight")
+                if tuple(w.shape[2:]) != ks:
+                    raise ops._l.Hi3dError(f"VideoDecoder: {q}.{n} has kernel {list(w.shape[2:])}, time_mix_conv {list(ks)}")
+                if self.iso:                     # [O, I, kt, ky, kx] -> three 2-D filters, one per frame offset
+                    for kt in range(3):
+                        W[f"{q}.{n}.w{kt}"] = pack.pack_conv3x3(w[:, :, kt])
+                else:
+                    W[f"{q}.{n}.w"] = pack.pack_convt3(w)
+                W[f"{q}.{n}.b"] = f32(f"{D}{q}.{n}.bias")
             W[p + ".alpha"] = torch.sigmoid(g(f"{D}{p}.mix_factor").float()).reshape(1)
-        oc = self.out_ch
-        W["tmix.w"] = f32(D + "conv_out.time_mix_conv.weight").reshape(oc, oc, 3).contiguous()
+        W["tmix.w"] = pack.f32(tm).contiguous() if self.iso else pack.f32(tm).reshape(oc, oc, 3).contiguous()
         W["tmix.b"] = f32(D + "conv_out.time_mix_conv.bias")
         self._T = None
+
+    def _conv3d_iso(self, hpad, key, b, T, H, Wd, C, R2=None, a1=None, out=None):
+        """Conv3d(C, C, 3, padding 1) of clip b: hpad [B, T + 2, H * W, C] (frames 0 and T + 1 zero) -> [T * H * W, C];
+        with R2 / a1 the tail a1 * (conv + bias) + R2 (AlphaBlender folded, see _resnet) rides the last launch."""
+        W, HW = self.W, H * Wd
+        geo = dict(Hin=H, Win=Wd, Cin=C, Hout=H, Wout=Wd, stride=1, up2x=0)
+        clip = hpad[b].reshape((T + 2) * HW, C)
+        acc = ops.gemm(clip[HW:], W[key + ".w1"], M=T * HW, N=C, K=9 * C, bias=W[key + ".b"], conv3x3=geo)            # frame t
+        acc = ops.gemm(clip, W[key + ".w0"], M=T * HW, N=C, K=9 * C, R1=acc, conv3x3=geo)                              # frame t - 1
+        return ops.gemm(clip[2 * HW:], W[key + ".w2"], M=T * HW, N=C, K=9 * C, R1=acc, R2=R2, a1=a1, out=out,           # frame t + 1
+                        rows_per_group=HW, conv3x3=geo)
 
     def _resnet(self, p, x, N, H, Wd, Cin, Cout):
         xs = super()._resnet(p, x, N, H, Wd, Cin, Cout)
         W, T, HW = self.W, self._T, H * Wd
         B = N // T
         q = p + ".time_stack"
+        if self.iso:
+            out = torch.empty_like(xs)
+            hpad = torch.zeros((B, T + 2, HW, Cout), device=xs.device, dtype=torch.bfloat16)
+            a1 = W[p + ".alpha"].expand(T).contiguous()
+            for b in range(B):
+                rows = slice(b * T * HW, (b + 1) * T * HW)
+                mid = hpad[b, 1:T + 1].reshape(T * HW, Cout)
+                ops.groupnorm_silu(xs[rows], W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], 1, T * HW, Cout, 1e-5, out=mid)
+                h = self._conv3d_iso(hpad, q + ".in_layers.2", b, T, H, Wd, Cout)
+                ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], 1, T * HW, Cout, 1e-5, out=mid)
+                self._conv3d_iso(hpad, q + ".out_layers.3", b, T, H, Wd, Cout, R2=xs[rows], a1=a1, out=out[rows])
+            return out
         tg = dict(T=T, HW=HW, Cin=Cout)
         h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5)
         h = ops.gemm(h, W[q + ".in_layers.2.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"], convt3=tg)
@@ -364,4 +404,6 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
 
     def _finish(self, out, N, H, Wd, ocp):
         # conv_out's 2-D result (fp32 [N*H*W, ocp]) -> time_mix_conv -> NCHW
+        if self.iso:
+            return ops.time_mix_small_k3(out, self.W["tmix.w"], self.W["tmix.b"], N // self._T, self._T, H, Wd, self.out_ch)
         return ops.time_mix_small(out, self.W["tmix.w"], self.W["tmix.b"], N // self._T, self._T, H, Wd, self.out_ch)

@@ -8,7 +8,7 @@ import torch
 from ..util import ParamTree, params_key
 
 
-def _shape_helpers(S):
+def _shape_helpers(S, vks=(3, 1, 1)):
     def conv(p, o, i, *k):
         S[p + ".weight"] = (o, i) + tuple(k); S[p + ".bias"] = (o,)
 
@@ -22,8 +22,8 @@ def _shape_helpers(S):
             conv(p + ".nin_shortcut", cout, cin, 1, 1)
         if temporal:        # VideoResBlock (temporal_ae.py:18-81): ResBlock(dims=3, skip_t_emb) + mix_factor
             q = p + ".time_stack"
-            norm(q + ".in_layers.0", cout); conv(q + ".in_layers.2", cout, cout, 3, 1, 1)
-            norm(q + ".out_layers.0", cout); conv(q + ".out_layers.3", cout, cout, 3, 1, 1)
+            norm(q + ".in_layers.0", cout); conv(q + ".in_layers.2", cout, cout, *vks)
+            norm(q + ".out_layers.0", cout); conv(q + ".out_layers.3", cout, cout, *vks)
             S[p + ".mix_factor"] = (1,)
 
     def mid(p, c, temporal=False):
@@ -63,12 +63,13 @@ def encoder_param_shapes(dd, prefix="encoder."):
     return S
 
 
-def decoder_param_shapes(dd, prefix="decoder.", temporal=False):
-    """Decoder (model.py:604-714) / VideoDecoder 'conv-only' (temporal_ae.py:293-349)."""
+def decoder_param_shapes(dd, prefix="decoder.", temporal=False, vks=(3, 1, 1)):
+    """Decoder (model.py:604-714) / VideoDecoder 'conv-only' (temporal_ae.py:293-349); vks = its video_kernel_size as a
+    (kt, ky, kx) triple: (3, 1, 1) as SVD / Hi3D configure it, (3, 3, 3) for the class default `video_kernel_size=3`."""
     _check_dd(dd)
     ch, mult, nres, zc = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"]
     S = {}
-    conv, norm, resnet, mid = _shape_helpers(S)
+    conv, norm, resnet, mid = _shape_helpers(S, tuple(vks))
     top = ch * mult[-1]
     conv(prefix + "conv_in", top, zc, 3, 3)
     mid(prefix + "mid", top, temporal)
@@ -82,7 +83,7 @@ def decoder_param_shapes(dd, prefix="decoder.", temporal=False):
     norm(prefix + "norm_out", cin)
     conv(prefix + "conv_out", dd["out_ch"], cin, 3, 3)
     if temporal:                                  # AE3DConv.time_mix_conv (temporal_ae.py:84-107)
-        conv(prefix + "conv_out.time_mix_conv", dd["out_ch"], dd["out_ch"], 3, 1, 1)
+        conv(prefix + "conv_out.time_mix_conv", dd["out_ch"], dd["out_ch"], *vks)
     return S
 
 

@@ -22,7 +22,8 @@ class Decoder(ParamTree):
     def __init__(self, **ddconfig):
         from ...models.autoencoder import decoder_param_shapes
         self.ddconfig = {k: v for k, v in ddconfig.items() if k not in ("video_kernel_size", "alpha", "merge_strategy", "time_mode")}
-        super().__init__(decoder_param_shapes(self.ddconfig, prefix="", temporal=self.temporal))
+        super().__init__(decoder_param_shapes(self.ddconfig, prefix="", temporal=self.temporal,
+                                              vks=tuple(getattr(self, "video_kernel_size", None) or (3, 1, 1))))
 
     def forward(self, *a, **k):
         raise RuntimeError("run through AutoencoderKL / AutoencodingEngine (MI355X runtime)")

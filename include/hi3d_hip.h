@@ -36,7 +36,13 @@ extern "C" {
 #define HI3D_ESHAPE -2      /* shape not supported by the gfx950 kernels      */
 #define HI3D_EALIGN -3      /* pointer / leading dimension alignment          */
 
-#define HI3D_ABI_VERSION 1
+/* Bumped whenever a struct of this header changes layout or an entry point changes its signature -- a caller built against an
+ * older header must refuse the library (hi3d_abi_version() != its HI3D_ABI_VERSION) instead of passing a shorter
+ * hi3d_gemm_desc, whose missing tail the library would read as garbage A2 / gn_partial / conv_taps.
+ *   1: rounds 1-4 (the descriptor GREW inside version 1 in round 4 -- A2, K1, lda2, gn_partial, w_group_stride, conv_ntap,
+ *      conv_taps -- which is the mistake this comment exists to prevent);
+ *   2: round 5 -- that descriptor, hi3d_time_mix_small_k3.                                                                 */
+#define HI3D_ABI_VERSION 2
 int hi3d_abi_version(void);
 /* static description of the last error on this host thread (never NULL) */
 const char* hi3d_last_error(void);
@@ -425,6 +431,13 @@ int hi3d_v02_blend(float* lat, const float* noise, const float* z, int64_t n, fl
  * x: fp32 channels-last [(b t)*HW][ldx] ; out: fp32 NCHW [(b t)][C][HW].               */
 int hi3d_time_mix_small(const float* x, const float* w, const float* b, float* out, int32_t B,
                         int32_t T, int32_t HW, int32_t C, int32_t ldx, void* stream);
+
+/* ... with video_kernel_size = 3, the reference class's default (temporal_ae.py:24,87-98: an int kernel size makes
+ * time_mix_conv an isotropic Conv3d(C, C, 3, padding 1)):
+ *   out[f][co][y][x] = b[co] + sum_{kt,ky,kx,ci} w[co][ci][kt][ky][kx] * x[f + kt - 1][y + ky - 1][x + kx - 1][ci]
+ * (zero outside the clip and the image).  x: fp32 channels-last [(b t)*H*W][ldx]; out: fp32 NCHW; C <= 4.        */
+int hi3d_time_mix_small_k3(const float* x, const float* w, const float* b, float* out, int32_t B,
+                           int32_t T, int32_t H, int32_t W, int32_t C, int32_t ldx, void* stream);
 
 /* Fused GEGLU feed-forward (FeedForward, sgm/modules/attention.py:83-119, as used by
  * BasicTransformerBlock attention.py:522-537 and VideoTransformerBlock video_attention.py:

@@ -216,13 +216,16 @@ def gen_v02(name, cfg, T, hw, steps, max_scale, wseed=1, iseed=0):
     print(f"{name}: final absmax {latents.abs().max():.4f} ({time.time() - t0:.1f}s)")
 
 
-def gen_video_decode(name, ch, b, T, hw, wseed=1, iseed=0):
+def gen_video_decode(name, ch, b, T, hw, wseed=1, iseed=0, vks=(3, 1, 1)):
+    """vks: VideoDecoder's video_kernel_size -- [3, 1, 1] is what SVD / Hi3D ship; the int 3 is the reference class's DEFAULT
+    (temporal_ae.py:24,87-92,299: an int makes time_stack and time_mix_conv isotropic Conv3d(3, padding 1))."""
     t0 = time.time()
+    vks = vks if isinstance(vks, int) else list(vks)
     AE = ref_import.ref("sgm.models.autoencoder.AutoencodingEngine")
     dd = vae_ddconfig(ch)
     ae = AE(encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
             decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
-                            "params": dict(dd, video_kernel_size=[3, 1, 1])},
+                            "params": dict(dd, video_kernel_size=vks)},
             loss_config={"target": "torch.nn.Identity"},
             regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"}).eval()
     synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
@@ -231,7 +234,7 @@ def gen_video_decode(name, ch, b, T, hw, wseed=1, iseed=0):
     with torch.no_grad():
         out = ae.decode(z, timesteps=T)
     sd = ae.state_dict()
-    fx = dict(kind="video_decode", ddconfig=dd, T=T, weight_seed=wseed, key_prefix=VAE_PREFIX, z=z, output=out,
+    fx = dict(kind="video_decode", ddconfig=dd, T=T, weight_seed=wseed, key_prefix=VAE_PREFIX, z=z, output=out, video_kernel_size=vks,
               shapes={k: tuple(v.shape) for k, v in sd.items()})
     torch.save(fx, os.path.join(GOLD, name + ".pt"))
     print(f"{name}: out {tuple(out.shape)} absmax {out.abs().max():.4f} ({time.time() - t0:.1f}s)")
@@ -297,6 +300,10 @@ def main():
         "engine_enc_tiny": lambda: gen_engine_encode("engine_enc_tiny", 64, 2, 64, iseed=8),
         "videodec_tiny": lambda: gen_video_decode("videodec_tiny", 64, 2, 3, 8),
         "videodec_full_lat8": lambda: gen_video_decode("videodec_full_lat8", 128, 1, 4, 8, iseed=3),
+        # video_kernel_size = 3, the reference class's default: isotropic 3 x 3 x 3 time_stack / time_mix_conv (two clips of 3
+        # frames at reduced width; one clip of 5 frames at full width, 128 x 128 pixels)
+        "videodec_tiny_k3": lambda: gen_video_decode("videodec_tiny_k3", 64, 2, 3, 8, iseed=21, vks=3),
+        "videodec_full_lat16_k3": lambda: gen_video_decode("videodec_full_lat16_k3", 128, 1, 5, 16, iseed=22, vks=3),
         "v02_tiny": lambda: gen_v02("v02_tiny", unet_cfg(2, 64), T=4, hw=8, steps=4, max_scale=2.0, iseed=6),
         "unet_s1_lat16": lambda: gen_unet("unet_s1_lat16", unet_cfg(1), T=4, hw=16, iseed=1),
         "unet_s2_lat16": lambda: gen_unet("unet_s2_lat16", unet_cfg(2), T=4, hw=16, iseed=2),

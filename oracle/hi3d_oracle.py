@@ -359,20 +359,22 @@ def v02_refine(sd, cfg, z_frames, init_noise, c, uc, T, num_steps, max_scale, al
 
 
 def video_decode(sd, dd, z, T, prefix="first_stage_model."):
-    """VideoDecoder.forward, time_mode 'conv-only', video_kernel_size [3,1,1]
-    (temporal_ae.py:18-107,293-349 on top of Decoder.forward model.py:715-748); z already divided
-    by scale_factor; no post_quant_conv (AutoencodingEngine)."""
+    """VideoDecoder.forward, time_mode 'conv-only' (temporal_ae.py:18-107,293-349 on top of Decoder.forward
+    model.py:715-748); video_kernel_size is read off the weights: [3,1,1] (SVD / Hi3D) or the class default 3 = isotropic
+    3x3x3, padding k // 2 either way (temporal_ae.py:87-98, openaimodel.py:257-261 with dims=3); z already divided by
+    scale_factor; no post_quant_conv (AutoencodingEngine)."""
     D = prefix + "decoder."
     n = z.shape[0]
     b = n // T
+    pad = lambda w: tuple(k // 2 for k in w.shape[2:])
 
     def vres(p, x):
         x = _vae_resnet(sd, p, x)
         c, hh, ww = x.shape[1:]
         x5 = x.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)
         q = p + ".time_stack"          # ResBlock(dims=3, skip_t_emb=True): openaimodel.py:328-354 without emb
-        h = F.conv3d(F.silu(_gn(sd, q + ".in_layers.0", x5, 1e-5)), sd[q + ".in_layers.2.weight"], sd[q + ".in_layers.2.bias"], padding=(1, 0, 0))
-        h = F.conv3d(F.silu(_gn(sd, q + ".out_layers.0", h, 1e-5)), sd[q + ".out_layers.3.weight"], sd[q + ".out_layers.3.bias"], padding=(1, 0, 0))
+        h = F.conv3d(F.silu(_gn(sd, q + ".in_layers.0", x5, 1e-5)), sd[q + ".in_layers.2.weight"], sd[q + ".in_layers.2.bias"], padding=pad(sd[q + ".in_layers.2.weight"]))
+        h = F.conv3d(F.silu(_gn(sd, q + ".out_layers.0", h, 1e-5)), sd[q + ".out_layers.3.weight"], sd[q + ".out_layers.3.bias"], padding=pad(sd[q + ".out_layers.3.weight"]))
         a = torch.sigmoid(sd[p + ".mix_factor"])
         out = a * (x5 + h) + (1.0 - a) * x5
         return out.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
@@ -391,7 +393,7 @@ def video_decode(sd, dd, z, T, prefix="first_stage_model."):
     h = F.conv2d(h, sd[D + "conv_out.weight"], sd[D + "conv_out.bias"], padding=1)          # AE3DConv: 2-D conv ...
     c, hh, ww = h.shape[1:]
     h5 = h.reshape(b, T, c, hh, ww).permute(0, 2, 1, 3, 4)                                   # ... then time_mix_conv
-    h5 = F.conv3d(h5, sd[D + "conv_out.time_mix_conv.weight"], sd[D + "conv_out.time_mix_conv.bias"], padding=(1, 0, 0))
+    h5 = F.conv3d(h5, sd[D + "conv_out.time_mix_conv.weight"], sd[D + "conv_out.time_mix_conv.bias"], padding=pad(sd[D + "conv_out.time_mix_conv.weight"]))
     return h5.permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
 
 

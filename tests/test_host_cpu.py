@@ -24,7 +24,7 @@ def test_c_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(hi3d_[a-z0-9_]+)\s*\(", header))
     declared -= {"hi3d_gemm_desc"}
     lib = hlib.load()
-    assert lib.hi3d_abi_version() == 1
+    assert lib.hi3d_abi_version() == hlib.ABI_VERSION == int(re.search(r"#define HI3D_ABI_VERSION (\d+)", header).group(1))
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/hi3d_hip.h but not exported"
     assert declared == set(hlib.EXPORTS), declared ^ set(hlib.EXPORTS)
@@ -262,13 +262,18 @@ def test_create_model_from_yaml_builds_engine():
         emb["cond_frames"](torch.zeros(1, 3, 64, 64))
 
 
-def test_autoencoding_engine_video_decoder_state_dict_matches_reference():
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_tiny_k3"])
+def test_autoencoding_engine_video_decoder_state_dict_matches_reference(name):
+    """VideoDecoder's state_dict (names and shapes) against the reference class's, for both kernel sizes the reference can
+    be configured with in practice: [3, 1, 1] (SVD / Hi3D) and the class DEFAULT 3 (temporal_ae.py:299) -- isotropic
+    [C, C, 3, 3, 3] time_stack convs and a [3, 3, 3, 3, 3] time_mix_conv."""
     from sgm.models.autoencoder import AutoencodingEngine
-    fx = load("videodec_tiny")
+    fx = load(name)
     dd = fx["ddconfig"]
+    vks = fx.get("video_kernel_size", [3, 1, 1])
     ae = AutoencodingEngine(
         encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
-        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(dd, video_kernel_size=[3, 1, 1])},
+        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(dd, video_kernel_size=vks)},
         loss_config={"target": "torch.nn.Identity"},
         regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"})
     assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == fx["shapes"]
@@ -276,6 +281,12 @@ def test_autoencoding_engine_video_decoder_state_dict_matches_reference():
     from sgm.modules.autoencoding.temporal_ae import VideoDecoder
     with pytest.raises(NotImplementedError, match="time_mode"):
         VideoDecoder(**dd, video_kernel_size=[3, 1, 1], time_mode="all")
+    # the constructor's default IS the isotropic kernel, as in the reference; sizes the kernels are not built for are refused
+    d = VideoDecoder(**dd)
+    assert d.video_kernel_size == [3, 3, 3] and tuple(d.state_dict()["conv_out.time_mix_conv.weight"].shape) == (3, 3, 3, 3, 3)
+    assert tuple(VideoDecoder(**dd, video_kernel_size=[3, 3, 3]).state_dict()["mid.block_1.time_stack.in_layers.2.weight"].shape[2:]) == (3, 3, 3)
+    with pytest.raises(NotImplementedError, match="video_kernel_size"):
+        VideoDecoder(**dd, video_kernel_size=5)
 
 
 def test_runtime_repack_key_sees_any_parameter_update():

@@ -888,6 +888,36 @@ def test_attention_temporal(dev, B, T, S, H):
     assert relerr(out, ref) < 2e-2
 
 
+@pytest.mark.parametrize("B,T,S,H", [(1, 32, 20, 3), (2, 17, 37, 2), (1, 24, 64, 5), (2, 31, 9, 1), (1, 32, 256, 20), (2, 16, 50, 2), (1, 5, 33, 1)])
+def test_attention_temporal_three_kernels_agree(dev, B, T, S, H, monkeypatch):
+    """hi3d_attn_temporal_d64 has three kernels: the one-block matrix-core kernel (T <= 16), the two-block matrix-core kernel of
+    round 5 (16 < T <= 32: BASELINE config 4's 32 views; HI3D_ATTNT_MFMA=2 sends every T through it) and the VALU kernel of rounds
+    1-3 (HI3D_ATTNT_MFMA=0).  Each against fp32 SDPA, the two-block kernel against the others on the same inputs, inside a
+    NaN-poisoned buffer (rows of frames >= T do not exist: nothing outside the [B*T*S, 3C] window may be read into a result)."""
+    from hi3d_hip import ops
+    C = H * 64
+    R = B * T * S
+    big = torch.full((R + 2 * 64, 3 * C), float("nan"), dtype=torch.bfloat16)
+    qkv = bf(rnd((R, 3 * C), 1) * 1.5)
+    big[64:64 + R] = qkv
+    q, k, v = [t.float().reshape(B, T, S, H, 64).permute(0, 2, 3, 1, 4).reshape(B * S, H, T, 64) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).reshape(B, S, H, T, 64).permute(0, 3, 1, 2, 4).reshape(R, C)
+    dbig = big.to(dev)
+    outs = {}
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("HI3D_ATTNT_MFMA", mode)
+        out = ops.attention_temporal_fused_qkv(dbig[64:64 + R], B, T, S, H)
+        assert torch.isfinite(out.float()).all(), mode
+        assert relerr(out, ref) < 2e-2, mode
+        outs[mode] = out.float().cpu()
+    # default dispatch (mode 1) takes the two-block kernel for T > 16 and the one-block kernel below: same arithmetic, the same
+    # P rounding; only the accumulation instruction of the second product differs (K = 32 with a zero block vs K = 16)
+    assert relerr(outs["2"], outs["1"]) < 4e-3
+    assert relerr(outs["2"], outs["0"]) < 1e-2
+    if T > 16:
+        assert torch.equal(outs["1"], outs["2"])
+
+
 @pytest.mark.parametrize("inst,P,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 100, 64, False, 1e-6),
                                                (2, 700, 960, True, 1e-5), (1, 64, 2560, True, 1e-5),
                                                (2, 4 * 64, 1280, True, 1e-5), (1, 1030, 128, True, 1e-6)])

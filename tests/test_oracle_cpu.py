@@ -123,7 +123,7 @@ def test_v02_refine_oracle_matches_reference():
     assert rel(out, fx["output"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32"])
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32", "videodec_tiny_k3", "videodec_full_lat16_k3"])
 def test_video_decoder_oracle_matches_reference(name):
     fx = load(name)
     with torch.no_grad():

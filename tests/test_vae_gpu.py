@@ -152,10 +152,12 @@ def test_conv3x3_bottom_right_padding(dev):
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1.2e-2
 
 
-@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32"])
+@pytest.mark.parametrize("name", ["videodec_tiny", "videodec_full_lat8", "videodec_full_lat32", "videodec_tiny_k3", "videodec_full_lat16_k3"])
 def test_video_decoder_matches_reference_golden(dev, name):
     """Temporal VAE decoder (north_star's 'AutoencoderKLTemporalDecoder' = VideoDecoder) through
-    AutoencodingEngine + the DiffusionEngine.decode_first_stage `timesteps` hook."""
+    AutoencodingEngine + the DiffusionEngine.decode_first_stage `timesteps` hook.  The *_k3 goldens were made with
+    video_kernel_size=3, the reference class's default (isotropic 3x3x3 time_stack / time_mix_conv); the others with the
+    [3, 1, 1] that SVD / Hi3D configure."""
     from hi3d_hip import synth
     from sgm.models.autoencoder import AutoencodingEngine
     from sgm.models.diffusion import DiffusionEngine
@@ -163,8 +165,10 @@ def test_video_decoder_matches_reference_golden(dev, name):
     dd = fx["ddconfig"]
     ae = AutoencodingEngine(
         encoder_config={"target": "sgm.modules.diffusionmodules.model.Encoder", "params": dd},
-        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder", "params": dict(dd, video_kernel_size=[3, 1, 1])},
+        decoder_config={"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
+                        "params": dict(dd, video_kernel_size=fx.get("video_kernel_size", [3, 1, 1]))},
         regularizer_config={"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"})
+    assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == {k: tuple(v) for k, v in fx["shapes"].items()}
     synth.fill_module_(ae, fx["weight_seed"], prefix=fx["key_prefix"])
     ae = ae.to(dev)
     out = ae.decode(fx["z"].to(dev), timesteps=fx["T"]).float().cpu()
