@@ -105,7 +105,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1", "tattn")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -286,3 +286,24 @@ def bench_conv_one():
 
 if len(sys.argv) > 1 and sys.argv[1] == "conv1":
     bench_conv_one()
+
+
+def bench_temporal_ab():
+    """usage: kbench.py tattn   -- hi3d_attn_temporal_d64's three kernels on the same inputs (HI3D_ATTNT_MFMA = 0: VALU kernel of
+    rounds 1-3, 1: default dispatch -- one-block matrix-core kernel for T <= 16, two-block above --, 2: two-block kernel for every
+    T), at the stage-2 levels for 16 and 32 views (B = 2 clips)."""
+    for T in (16, 32):
+        for ds, C in ((1, 320), (2, 640), (4, 1280)):
+            S, H = (128 // ds) ** 2, C // 64
+            qkv = rb(2 * T * S, 3 * C)
+            line = f"  T={T} S={S:6d} H={H:2d}:"
+            for mode in ("0", "1", "2"):
+                os.environ["HI3D_ATTNT_MFMA"] = mode
+                ms = timeit(lambda: ops.attention_temporal_fused_qkv(qkv, 2, T, S, H))
+                line += f"   mode {mode}: {ms:7.3f} ms {2.0 * 4 * 2 * T * S * C / ms / 1e6:7.1f} GB/s"
+            os.environ.pop("HI3D_ATTNT_MFMA", None)
+            print(line, flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "tattn":
+    bench_temporal_ab()
