@@ -155,6 +155,10 @@ class FrameSpaceGroup:
             raise ValueError(f"pixels per frame ({S}) must be a multiple of the frame-parallel degree ({self.world})")
         return S // self.world
 
+    # HI3D_A2A_POISON=1 (tests): every exchange fills the receive buffer it is NOT about to use with NaN, so a caller that still
+    # holds the result of the second-last exchange of this shape reads NaN instead of silently stale rows (see frames_to_space)
+    _POISON = __import__("os").environ.get("HI3D_A2A_POISON", "0") == "1"
+
     def _recv_buffer(self, send):
         """Persistent receive buffers, two per exchange shape used alternately: a step makes 76 exchanges of ~6 shapes, and a
         fresh allocation per exchange (round 3) put an allocator call -- and, under RCCL, a stream-recorded block that the
@@ -167,6 +171,8 @@ class FrameSpaceGroup:
         if ent is None:
             ent = self._recv[key] = [[torch.empty_like(send), torch.empty_like(send)], 0]
         ent[1] ^= 1
+        if self._POISON and send.dtype.is_floating_point:
+            ent[0][ent[1] ^ 1].fill_(float("nan"))
         return ent[0][ent[1]]
 
     def _a2a(self, send):
@@ -190,10 +196,20 @@ class FrameSpaceGroup:
         if x.is_cuda:
             from . import ops
             return ops.permute_rows(x.contiguous(), list(dims), list(perm))
-        return x.reshape(*dims, -1).permute(*perm, 4).contiguous()
+        y = x.reshape(*dims, -1).permute(*perm, 4).contiguous()
+        # ALWAYS a copy, like the HIP kernel: with a size-1 axis the permuted view is already contiguous and .contiguous() hands
+        # back x's own storage -- for `recv` that is the persistent receive buffer, and a caller keeping the result (the UNet's
+        # skip tensors do) would see it overwritten two exchanges later (found by the 8-rank two-communicator test: B * Tl = 1)
+        return y.clone() if y.data_ptr() == x.data_ptr() else y
 
     def frames_to_space(self, x, B, S):
-        """[B*Tl*S, C] (b tl s) -> [B*T*Sl, C] (b t sl)"""
+        """[B*Tl*S, C] (b tl s) -> [B*T*Sl, C] (b t sl).
+
+        LIFETIME (B == 1, the CFG-split mapping): the result is a VIEW of one of the two persistent receive buffers of this
+        shape -- no unpack copy is needed, so none is made -- and stays valid until the SECOND-next exchange of the same shape.
+        Both callers (runtime_unet._res / _transformer) consume it inside their block, before the block's own
+        space_to_frames: do not keep it (as a skip tensor, say) beyond that; space_to_frames always returns a fresh tensor.
+        HI3D_A2A_POISON=1 turns a violation into NaNs (tests/test_parallel_gpu.py runs the clip-parallel step under it)."""
         w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
         if w == 1:
             return x
@@ -287,12 +303,26 @@ class ClipParallelStepper:
 
     x / the returned latent are the FULL [T,4,h,w] fp32 state (replicated, 4 MB at stage 2)."""
 
-    def __init__(self, unet, guider, T, cfg=2, group=None, sp_group=None):
+    def __init__(self, unet, guider, T, cfg=2, group=None, sp_group=None, overlap=False):
+        """overlap (cfg == 1 only -- e.g. cfg 1 x sp 8 on one node): the two CFG halves a rank holds run as two chains on two HIP
+        streams, each with its OWN communicator over the same ranks (a second dist.new_group: collectives of one communicator
+        are serialised, two communicators are not), so the all-to-all of one half travels while the other half's spatial
+        sub-block computes.  In the cfg 2 mapping a rank holds ONE half and has no such independent work."""
         from . import ops  # noqa: F401  (needs the HIP library: GPU only)
         self.unet, self.guider, self.T, self.cfg = unet, guider, T, cfg
         self.group = group
         self.sp, self.half, self.part, self.sp_group = clip_parallel_groups(group, cfg, sp_group)
         self.comm = FrameSpaceGroup(T, self.sp_group)
+        self.comm2 = None
+        if overlap:
+            if cfg != 1:
+                raise ValueError("overlap needs cfg == 1 (a rank must hold both CFG halves to have independent work)")
+            if self.sp > 1:
+                members = tuple(dist.get_process_group_ranks(self.sp_group))
+                g2 = _SP_GROUPS.get((members, "second"))
+                if g2 is None:
+                    g2 = _SP_GROUPS[(members, "second")] = dist.new_group(list(members), use_local_synchronization=True)
+                self.comm2 = FrameSpaceGroup(T, g2)
         self.gather_bytes = 0
         self._host_staged = dist.get_backend(group) == "gloo"
         self._clip = None
@@ -352,7 +382,8 @@ class ClipParallelStepper:
             tok = tok2 if B == 2 else tok2[self.half * Tl * HW:(self.half + 1) * Tl * HW]
             tv_full.copy_(tv_l[:1].expand(2 * T))
             tvec = tv_full[:B * T]
-            net = rt.forward_tokens(tok, B * T, H, W, tvec, st, T, sp=self.comm)            # [B*Tl*HW, 4] fp32
+            sp = self.comm if self.comm2 is None else (self.comm, self.comm2)             # (pair: two chains, two communicators)
+            net = rt.forward_tokens(tok, B * T, H, W, tvec, st, T, sp=sp)                   # [B*Tl*HW, 4] fp32
             world = self.cfg * self.sp
             full = torch.empty((world * net.shape[0], net.shape[1]), device=dev, dtype=net.dtype)   # rank-major concatenation
             if self._host_staged:

@@ -407,11 +407,19 @@ class UNetRuntime:
 
         Frame-parallel (`sp` = hi3d_hip.parallel.FrameSpaceGroup over w GPUs): F, timesteps and
         st still describe the WHOLE batch of B*T frames; x_tok holds this GPU's B*T/w frames (clip-major)
-        and so does the result."""
+        and so does the result.  `sp` may also be a PAIR of groups over the same ranks, one per CFG half of a B = 2 batch
+        (the cfg 1 x sp w mapping with overlap, ClipParallelStepper(overlap=True)): the two halves -- which never mix inside
+        the network -- then run as two independent kernel + collective chains on two HIP streams, each on its own
+        communicator, so one half's all-to-all / all-reduce is in flight while the other half computes."""
         W, mc = self.W, self.mc
         if F_ % T:
             raise ops._l.Hi3dError("batch is not a multiple of num_video_frames")
         B_all = F_ // T
+        sp_pair = None
+        if isinstance(sp, (tuple, list)):
+            if len(sp) != 2 or B_all != 2 or sp[0].world != sp[1].world or sp[0].rank != sp[1].rank:
+                raise ops._l.Hi3dError("a pair of frame-parallel groups needs a B = 2 batch (uncond || cond) and two groups over the same ranks")
+            sp_pair, sp = (sp[0], sp[1]), sp[0]
         # ---- embeddings (video_model.py:456-469): emb = time_embed(t) + label_emb(y)
         te = ops.timestep_embedding(timesteps, mc, 10000.0, out_bf16=True)
         h = self._linear(te, "time_embed.0", F_, out_fp32=True)
@@ -454,7 +462,7 @@ class UNetRuntime:
                                  conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
                     cur["C"] = mc
                 elif L[0] == "res":
-                    h = self._res(p, h, L[1], L[2], F_c, Hc, Wc, T, c.emb, c.a1, emb_full=emb_full, x2=h2, **c.kw)
+                    h = self._res(p, h, L[1], L[2], F_c, Hc, Wc, T, c.emb, c.a1, emb_full=getattr(c, "emb_full", emb_full), x2=h2, **c.kw)
                     h2 = None
                     cur["C"] = L[2]
                 elif L[0] == "attn":
@@ -494,6 +502,45 @@ class UNetRuntime:
 
         full = make_ctx(F_, emb_all, cond, a1_all, a_all, kw)
         cur = {"H": H, "W": Wd, "C": CIN_PAD}
+        if sp_pair is not None and sp is not None:
+            # ---- cfg 1 x sp w with overlap: the whole network as two chains (half 0 = unconditional on the caller's stream,
+            # half 1 = conditional on the side stream), B = 1 each, every exchange of a chain on that chain's communicator.
+            # The host issues chain 1 first and whole (its kernels and collectives queue on the side stream), then chain 0: on
+            # the GPU the two streams advance side by side, and a chain that waits for its all-to-all leaves the CUs to the other.
+            Tl = F_ // 2                                         # this GPU's frames per half (F_ is the local frame count here)
+            for pt, Ct in self.transformers:                     # per-clip constants of the B = 1 shape: made before the fork
+                self._pos_emb(pt, Ct, 1, T)
+            main = torch.cuda.current_stream()
+            side = main if ops.PROFILER is not None else self._side_stream()
+            out = torch.empty((F_ * H * Wd, oc), device=x_tok.device, dtype=torch.float32)
+            rows, orows = x_tok.shape[0] // 2, out.shape[0] // 2
+            chains = []
+            for hf in (0, 1):
+                fs, ft = slice(hf * Tl, (hf + 1) * Tl), slice(hf * T, (hf + 1) * T)
+                # (spatial-block vectors: one row per LOCAL frame; temporal-block vectors: one row per clip)
+                cond_h = {k: (v[fs] if v.shape[0] == F_ else v[hf:hf + 1]) for k, v in cond.items()}
+                c = make_ctx(Tl, emb_all[fs], cond_h, a1_all[:, ft], a_all[:, ft], dict(sp=sp_pair[hf], B=1))
+                c.emb_full = emb_full[ft]                         # the temporal sub-blocks see all T frames of the half
+                chains.append(c)
+
+            def chain(hf):
+                c, cur_h = chains[hf], dict(cur)
+                h_, hs_ = x_tok[hf * rows:(hf + 1) * rows], []
+                for i, layers in enumerate(blocks_in):
+                    h_ = run(c, cur_h, h_, layers, f"input_blocks.{i}")
+                    hs_.append((h_, cur_h["C"]))
+                h_ = run(c, cur_h, h_, middle, "middle_block")
+                for i, layers in enumerate(blocks_out):
+                    s_, sc_ = hs_.pop()
+                    h_ = run_out_block(c, cur_h, h_, i, layers, s_, sc_)
+                head(c, cur_h, h_, out[hf * orows:(hf + 1) * orows])
+
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                chain(1)
+            chain(0)
+            main.wait_stream(side)
+            return out
         want_two = self.two_stream == "1" or (self.two_stream == "auto" and F_ * H * Wd >= (1 << 18))
         n_split_in, n_split_out = self._split_plan() if (want_two and sp is None and B_all == 2 and F_ % 2 == 0) else (0, 0)
         if not n_split_in:

@@ -141,43 +141,60 @@ def test_frame_space_all_to_all_layouts():
         assert res[0][(2, 8)][4] == 3 * (B * T * S * C * 4 // world) * (world - 1) // world
 
 
-def _sharded_unet_job(rank, world):
-    import torch
-    from hi3d_hip import synth
-    from hi3d_hip.parallel import FrameSpaceGroup
-    from oracle import hi3d_oracle_sharded as OS
+def _sharded_case(world):
+    """(T, H, W, B): every level's pixel count and T must divide by the frame-parallel degree -- 2 ranks: the round-2 case;
+    8 ranks (one whole MI355X node as cfg 1 x sp 8): 8 frames, 32 x 32 latents (4 x 4 = 16 pixels at the lowest level)"""
+    return (4, 16, 8, 2) if world <= 2 else (8, 32, 32, 2)
+
+
+def _sharded_inputs(world):
     fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_s2_ioi.pt"), weights_only=False)
+    from hi3d_hip import synth
     cfg, P = fx["cfg"], fx["key_prefix"]
     sd = synth.synth_state_dict({P + k: v for k, v in fx["shapes"].items()}, fx["weight_seed"])
-    T, H, W, B = 4, 16, 8, 2
+    T, H, W, B = _sharded_case(world)
     g = torch.Generator().manual_seed(5)
     x = torch.randn((B * T, cfg["in_channels"], H, W), generator=g)
     ctx, y = torch.randn((B, 1, 1024), generator=g), torch.randn((B, cfg["adm_in_channels"]), generator=g)
     ioi = torch.zeros(B, T); ioi[1, 2] = 1.0
+    return cfg, P, sd, x, ctx, y, ioi, T, B
+
+
+def _sharded_unet_job(rank, world):
+    from hi3d_hip.parallel import FrameSpaceGroup
+    from oracle import hi3d_oracle_sharded as OS
+    cfg, P, sd, x, ctx, y, ioi, T, B = _sharded_inputs(world)
     comm = FrameSpaceGroup(T)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     with torch.no_grad():
         out = OS.video_unet_sharded(sd, cfg, x[comm.local_frames(B)], 0.37, ctx, y, T, ioi, comm, prefix=P)
     return out, comm.n_switches, comm.n_allreduce, comm.bytes_moved
 
 
-def test_unet_frame_space_sharded_equals_unsharded_oracle():
-    """Two ranks, each holding half the frames (spatial sub-blocks) / half the pixels (temporal
-    sub-blocks) of the same 2-clip batch, with the 3-D GroupNorm partial-sum all-reduce: the
-    concatenation of the ranks' outputs must equal the single-process oracle forward."""
-    from hi3d_hip import synth
+def _sharded_unet_two_comm_job(rank, world):
+    """cfg 1 x sp `world` with the OVERLAP decomposition of ClipParallelStepper(overlap=True): a rank holds both CFG halves of
+    its frames and runs them as two independent chains, each on its OWN communicator over the same ranks (B = 1 per chain:
+    one half's exchange can then run beside the other half's spatial sub-block).  Here the chains run one after the other
+    (gloo is blocking); what is checked is the decomposition: two B = 1 passes on two process groups == the B = 2 pass."""
+    from hi3d_hip.parallel import FrameSpaceGroup
+    from oracle import hi3d_oracle_sharded as OS
+    cfg, P, sd, x, ctx, y, ioi, T, B = _sharded_inputs(world)
+    ranks = list(range(world))
+    comms = [FrameSpaceGroup(T, dist.new_group(ranks)) for _ in range(B)]
+    torch.set_num_threads(1)
+    outs = []
+    with torch.no_grad():
+        for b in (1, 0):                        # (the side chain is issued first, as forward_tokens does)
+            xb = x[b * T:(b + 1) * T][comms[b].local_frames(1)]
+            outs.append((b, OS.video_unet_sharded(sd, cfg, xb, 0.37, ctx[b:b + 1], y[b:b + 1], T, ioi[b:b + 1], comms[b], prefix=P)))
+    outs.sort(key=lambda t: t[0])
+    return torch.cat([o for _, o in outs], 0), [c.n_switches for c in comms], [c.n_allreduce for c in comms], sum(c.bytes_moved for c in comms)
+
+
+def _check_sharded(res, world, two_comm=False):
     from hi3d_hip.runtime_unet import unet_layout
     from oracle import hi3d_oracle as O
-    world = 2
-    res = spawn(_sharded_unet_job, world)
-    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_tiny_s2_ioi.pt"), weights_only=False)
-    cfg, P = fx["cfg"], fx["key_prefix"]
-    sd = synth.synth_state_dict({P + k: v for k, v in fx["shapes"].items()}, fx["weight_seed"])
-    T, H, W, B = 4, 16, 8, 2
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn((B * T, cfg["in_channels"], H, W), generator=g)
-    ctx, y = torch.randn((B, 1, 1024), generator=g), torch.randn((B, cfg["adm_in_channels"]), generator=g)
-    ioi = torch.zeros(B, T); ioi[1, 2] = 1.0
+    cfg, P, sd, x, ctx, y, ioi, T, B = _sharded_inputs(world)
     with torch.no_grad():
         ref = O.video_unet(sd, cfg, x, torch.full((B * T,), 0.37), ctx, y, T, ioi, prefix=P)
     Tl = T // world
@@ -186,13 +203,35 @@ def test_unet_frame_space_sharded_equals_unsharded_oracle():
         idx = torch.cat([torch.arange(b * T + r * Tl, b * T + (r + 1) * Tl) for b in range(B)])
         got[idx] = res[r][0]
     err = ((got - ref).abs().max() / ref.abs().max()).item()
-    print(f"frame<->space sharded oracle vs unsharded: rel {err:.2e}")
+    print(f"frame<->space sharded oracle vs unsharded, {world} ranks{' (one communicator per CFG half)' if two_comm else ''}: rel {err:.2e}")
     assert err < 2e-5
     # the plan: two switches per VideoResBlock and per SpatialVideoTransformer, two sum all-reduces per 3-D ResBlock
     bi, mid, bo = unet_layout(cfg)
     layers = [L for blk in bi + [mid] + bo for L in blk]
     nres, nattn = sum(L[0] == "res" for L in layers), sum(L[0] == "attn" for L in layers)
-    assert res[0][1] == 2 * (nres + nattn) and res[0][2] == 2 * nres
+    if two_comm:
+        assert res[0][1] == [2 * (nres + nattn)] * B and res[0][2] == [2 * nres] * B
+    else:
+        assert res[0][1] == 2 * (nres + nattn) and res[0][2] == 2 * nres
+    return res[0][3]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_unet_frame_space_sharded_equals_unsharded_oracle(world):
+    """`world` ranks, each holding 1/world of the frames (spatial sub-blocks) / of the pixels (temporal sub-blocks) of the same
+    2-clip batch, with the 3-D GroupNorm partial-sum all-reduce: the concatenation of the ranks' outputs must equal the
+    single-process oracle forward.  8 ranks = one whole node as cfg 1 x sp 8."""
+    _check_sharded(spawn(_sharded_unet_job, world), world)
+
+
+def test_unet_two_communicators_one_per_cfg_half_8_ranks():
+    """The decomposition behind the all-to-all / compute overlap of the cfg 1 x sp 8 mapping: the two CFG halves as two B = 1
+    chains on two communicators over the same 8 ranks reproduce the unsharded oracle, move the same bytes as the joint B = 2
+    pass and issue the same number of collectives per chain."""
+    world = 8
+    moved_two = _check_sharded(spawn(_sharded_unet_two_comm_job, world), world, two_comm=True)
+    moved_joint = spawn(_sharded_unet_job, world)[0][3]
+    assert moved_two == moved_joint
 
 
 def _groups_job(rank, world):

@@ -74,11 +74,13 @@ def _case_full(dev):
     return fx, unet, guider, T, x0 * 700.0, c, uc, sigmas
 
 
-def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo"):
+def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo", overlap=False, poison=False):
     for p in (os.path.join(ROOT, "hi3d-official_amd"), ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if poison:          # (read when hi3d_hip.parallel is imported, below: the receive buffer NOT in use is NaN-filled at every exchange)
+        os.environ["HI3D_A2A_POISON"] = "1"
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -88,13 +90,15 @@ def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo"):
     try:
         from hi3d_hip.parallel import ClipParallelStepper
         fx, unet, guider, T, x, c, uc, sigmas = (_case_full if case == "full" else _case)(dev)
-        stepper = ClipParallelStepper(unet, guider, T, cfg=cfg)
+        stepper = ClipParallelStepper(unet, guider, T, cfg=cfg, overlap=overlap)
         x = x.to(dev)
         cd = {k: v.to(dev) for k, v in c.items()}
         ucd = {k: v.to(dev) for k, v in uc.items()}
         for i in range(2):                            # two steps: the second reuses the per-clip constants
             x = stepper.step(x, sigmas.to(dev), i, cd, ucd, torch.zeros(2 // cfg, T, device=dev))
-        ret[rank] = (x.cpu(), stepper.comm.n_switches, stepper.comm.n_allreduce, stepper.comm.bytes_moved, stepper.gather_bytes)
+        comms = [stepper.comm] + ([stepper.comm2] if stepper.comm2 is not None else [])
+        ret[rank] = (x.cpu(), sum(c.n_switches for c in comms), sum(c.n_allreduce for c in comms), sum(c.bytes_moved for c in comms),
+                     stepper.gather_bytes)
     finally:
         dist.destroy_process_group()
 
@@ -168,6 +172,32 @@ def test_clip_parallel_full_width_matches_single_gpu(dev, world, cfg):
         print(f"full width, world {world} cfg {cfg} rank {r}: rel {rel:.2e}")
         assert rel < 5e-3
         assert torch.equal(got, ret[0][0]), "every rank must hold the same next latent"
+
+
+@pytest.mark.parametrize("case", ["tiny", "full"])
+def test_clip_parallel_cfg1_overlap_two_communicators(dev, case):
+    """cfg 1 x sp 2 with overlap (the mapping bench.py --gpus 8 reports as cfg1 x sp8): each rank runs the two CFG halves as two
+    chains on two HIP streams, each chain's all-to-alls / all-reduces on its own communicator (ClipParallelStepper(overlap=
+    True), runtime_unet.forward_tokens(sp=(g0, g1))).  Against the single-process step, at the tiny and at the FULL width;
+    every rank the same latent; twice the collectives of the joint B = 2 pass at half the size (the same bytes); and with
+    HI3D_A2A_POISON=1 -- the idle receive buffer NaN-filled at every exchange -- so a result of frames_to_space held too long
+    (its B = 1 form is a view of a persistent buffer) would surface as NaN instead of stale rows."""
+    ref, fx = _reference(dev, case)
+    torch.cuda.empty_cache()
+    mgr = mp.Manager()
+    ret, ret_joint = mgr.dict(), mgr.dict()
+    mp.spawn(_rank_main, args=(2, _free_port(), 1, ret, case, "gloo", True, True), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, _free_port(), 1, ret_joint, case, "gloo", False, True), nprocs=2, join=True)
+    for r in range(2):
+        got = ret[r][0]
+        assert torch.isfinite(got).all() and torch.isfinite(ret_joint[r][0]).all()
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        relj = ((got - ret_joint[r][0]).abs().max() / ref.abs().max()).item()
+        print(f"{case}: cfg1 x sp2 overlap rank {r}: rel {rel:.2e} vs single process, {relj:.2e} vs the joint B = 2 pass")
+        assert rel < 5e-3 and relj < 5e-3
+        assert torch.equal(got, ret[0][0]), "every rank must hold the same next latent"
+        # two chains: every collective of the joint pass twice, half the rows each -- the same bytes
+        assert ret[r][1] == 2 * ret_joint[r][1] and ret[r][2] == 2 * ret_joint[r][2] and ret[r][3] == ret_joint[r][3]
 
 
 def _vae_case(dev):
