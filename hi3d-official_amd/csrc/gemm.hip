@@ -1158,6 +1158,11 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   return dispatch<2, 4, 2>(p, amode, d->epi, s);
 }
 
+// 1 when the LAST hi3d_gemm_bf16 launch of the calling host thread filled its descriptor's gn_partial, 0 when it did not (the
+// consumer then runs the full hi3d_groupnorm_silu): the answer hi3d_gemm_gn_partial_supported gives BEFORE a launch, without the
+// second pass through the dispatch (the wrappers probed, then launched -- every eager conv paid the host side twice)
+extern "C" int hi3d_gemm_last_gn_fused(void) { return g_gn_fused; }
+
 // debug aid: resident blocks per CU the runtime predicts for a kernel variant
 extern "C" int hi3d_debug_gemm_occupancy(int wm, int nt, int ns) {
   int n = -1;

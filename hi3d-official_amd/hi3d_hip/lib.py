@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libhi3d_hip.so")
 EXPORTS = [
     "hi3d_abi_version", "hi3d_last_error", "hi3d_gemm_bf16", "hi3d_gemm_set_workspace", "hi3d_gemm_set_workspace_for_stream", "hi3d_debug_gemm_launch_info", "hi3d_debug_gemm_launch_info_on", "hi3d_attn_d64", "hi3d_attn_d64_v", "hi3d_attn_d512",
     "hi3d_transpose_v", "hi3d_attn_temporal_d64", "hi3d_attn_fp8_workspace_bytes", "hi3d_attn_quant_qk", "hi3d_attn_d64_fp8qk", "hi3d_attn_fp8_v_workspace_bytes", "hi3d_attn_quant_v", "hi3d_attn_d64_fp8", "hi3d_gn_partial_blocks",
-    "hi3d_gn_workspace_floats", "hi3d_groupnorm_silu", "hi3d_groupnorm_silu_cat2", "hi3d_groupnorm_silu_from_partials", "hi3d_gemm_gn_partial_supported", "hi3d_groupnorm_partial_sums", "hi3d_groupnorm_apply_sums", "hi3d_layernorm",
+    "hi3d_gn_workspace_floats", "hi3d_groupnorm_silu", "hi3d_groupnorm_silu_cat2", "hi3d_groupnorm_silu_from_partials", "hi3d_gemm_gn_partial_supported", "hi3d_gemm_last_gn_fused", "hi3d_groupnorm_partial_sums", "hi3d_groupnorm_apply_sums", "hi3d_layernorm",
     "hi3d_concat_channels", "hi3d_timestep_embedding", "hi3d_silu_f32_to_bf16",
     "hi3d_cfg_prepare", "hi3d_sampler_step", "hi3d_cfg_update_x", "hi3d_sampler_step_dev", "hi3d_nchw_f32_to_nhwc_bf16",
     "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows", "hi3d_vae_posterior", "hi3d_v02_blend", "hi3d_time_mix_small", "hi3d_time_mix_small_k3", "hi3d_ffn_geglu", "hi3d_ffn_geglu_ln", "hi3d_groupnorm_fold_linear",
@@ -88,6 +88,7 @@ def load():
         "hi3d_groupnorm_silu": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]),
         "hi3d_groupnorm_silu_from_partials": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]),
         "hi3d_gemm_gn_partial_supported": (C.c_int, [C.POINTER(GemmDesc), vp]),
+        "hi3d_gemm_last_gn_fused": (C.c_int, []),
         "hi3d_groupnorm_silu_cat2": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
         "hi3d_groupnorm_partial_sums": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "hi3d_groupnorm_apply_sums": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, i32, vp]),

@@ -164,12 +164,11 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     if gn is not None and GN_FUSED and gn[1] % 64 == 0 and gn[0] * gn[1] == M:
         gn_ws = _gn_workspace(A.device, gn[0], gn[1], n_out)
         d.gn_partial = _p(gn_ws)
-        if _lib.hi3d_gemm_gn_partial_supported(d, _stream()) != 1:
-            d.gn_partial, gn_ws = 0, None
-    n_out = N // 2 if geglu else N
     prof = PROFILER
     t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")
+    if gn_ws is not None and _lib.hi3d_gemm_last_gn_fused() != 1:        # (asked after the launch: one pass through the dispatch)
+        gn_ws = None
     if prof:
         fam = ("gemm_conv3x3" if conv3x3 is not None else "gemm_convt3" if convt3 is not None else "gemm_dense")
         nres = (R1 is not None) + (R2 is not None)

@@ -54,10 +54,14 @@ UP_PHASES = os.environ.get("HI3D_UP_PHASES", "1") != "0"   # up-sampling convs a
 _SIDE = {}
 
 
-def run_chunks(fn, chunks, device):
+def run_chunks(fn, chunks, device, prepare=None):
     """[fn(lo, hi) for lo, hi in chunks], chunk i on stream i % VAE_STREAMS (0 = the caller's; the side streams are joined before
-    returning); fn returns one tensor."""
+    returning); fn returns one tensor.  prepare(): called first, on the caller's stream -- the engine builds the model's HIP
+    runtime there (weight re-layout), so that nothing a side stream reads is still being made (do not rely on chunk
+    0 for that); per-stream state (split-K / GroupNorm scratch, grown on demand for a ragged last chunk) is keyed by stream."""
     dev = torch.device(device)
+    if prepare is not None:
+        prepare()
     n = min(VAE_STREAMS, len(chunks))
     if dev.type != "cuda" or n < 2 or ops.PROFILER is not None or torch.cuda.is_current_stream_capturing():
         return [fn(lo, hi) for lo, hi in chunks]                 # (per-kernel timing wants kernels that do not share the chip)

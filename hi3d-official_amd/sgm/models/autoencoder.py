@@ -187,18 +187,30 @@ class AutoencodingEngine(torch.nn.Module):
     def _key(self, device):
         return params_key(self, device)
 
+    def runtime(self, device):
+        """the decoder's HIP runtime (weights re-laid-out once per parameter state), as AutoencoderKL.runtime"""
+        from hi3d_hip.runtime_vae import VAEDecoderRuntime, VideoDecoderRuntime
+        key = self._key(device)
+        if self._dec_rt is None or self._dec_key != key:
+            cls = VideoDecoderRuntime if self.is_video_decoder else VAEDecoderRuntime
+            self._dec_rt, self._dec_key = cls(self.state_dict(), self.decoder.ddconfig, device), key
+        return self._dec_rt
+
+    def encoder_runtime(self, device):
+        from hi3d_hip.runtime_vae import VAEEncoderRuntime
+        key = self._key(device)
+        if self._enc_rt is None or self._enc_key != key:
+            self._enc_rt, self._enc_key = VAEEncoderRuntime(self.state_dict(), self.encoder.ddconfig, device), key
+        return self._enc_rt
+
     @torch.no_grad()
     def decode(self, z, **kwargs):
         if not z.is_cuda:
             raise RuntimeError("decode runs on the MI355X only (no CPU path in this framework)")
-        from hi3d_hip.runtime_vae import VAEDecoderRuntime, VideoDecoderRuntime
-        key = self._key(z.device)
-        if self._dec_rt is None or self._dec_key != key:
-            cls = VideoDecoderRuntime if self.is_video_decoder else VAEDecoderRuntime
-            self._dec_rt, self._dec_key = cls(self.state_dict(), self.decoder.ddconfig, z.device), key
+        rt = self.runtime(z.device)
         if self.is_video_decoder:
-            return self._dec_rt.decode(z, timesteps=kwargs.get("timesteps")).to(z.dtype)
-        return self._dec_rt.decode(z).to(z.dtype)
+            return rt.decode(z, timesteps=kwargs.get("timesteps")).to(z.dtype)
+        return rt.decode(z).to(z.dtype)
 
     @torch.no_grad()
     def encode(self, x, return_reg_log=False, unregularized=False, noise=None):
@@ -207,14 +219,11 @@ class AutoencodingEngine(torch.nn.Module):
         like the reference's torch.randn(...).to(device) unless `noise` is given -- or .mode() with `sample: false`."""
         if not x.is_cuda:
             raise RuntimeError("encode runs on the MI355X only (no CPU path in this framework)")
-        from hi3d_hip.runtime_vae import VAEEncoderRuntime
-        key = self._key(x.device)
-        if self._enc_rt is None or self._enc_key != key:
-            self._enc_rt, self._enc_key = VAEEncoderRuntime(self.state_dict(), self.encoder.ddconfig, x.device), key
+        rt = self.encoder_runtime(x.device)
         if unregularized:
-            return self._enc_rt.encode(x, moments=True).to(x.dtype), {}
+            return rt.encode(x, moments=True).to(x.dtype), {}
         n, _, h, w = x.shape
         if self.sample_posterior and noise is None:
             noise = torch.randn((n, self.encoder.ddconfig["z_channels"], h // 8, w // 8))
-        z = self._enc_rt.encode(x, noise if self.sample_posterior else None).to(x.dtype)
+        z = rt.encode(x, noise if self.sample_posterior else None).to(x.dtype)
         return (z, {}) if return_reg_log else z

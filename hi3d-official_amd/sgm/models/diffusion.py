@@ -81,6 +81,16 @@ class DiffusionEngine(nn.Module):
         step = default(self.en_and_decode_n_samples_a_time, n)
         return [(i, min(n, i + step)) for i in range(0, n, step)]
 
+    def _build_first_stage_runtime(self, device, which):
+        """The first-stage model's HIP runtime (weight re-layout) built NOW, on the caller's stream, before the chunk loop lets
+        side streams run (hi3d_hip.runtime_vae.run_chunks); a no-op once built and for models without the hook."""
+        if device.type != "cuda":
+            return
+        m = self.first_stage_model
+        fn = getattr(m, "runtime" if which == "decode" else "encoder_runtime", None)
+        if fn is not None:
+            fn(device)
+
     @torch.no_grad()
     def decode_first_stage(self, z):
         from hi3d_hip.runtime_vae import run_chunks
@@ -92,7 +102,7 @@ class DiffusionEngine(nn.Module):
                 kwargs["timesteps"] = hi - lo
             return self.first_stage_model.decode(z[lo:hi], **kwargs)
 
-        return torch.cat(run_chunks(one, self._chunks(z.shape[0]), z.device), dim=0)
+        return torch.cat(run_chunks(one, self._chunks(z.shape[0]), z.device, prepare=lambda: self._build_first_stage_runtime(z.device, "decode")), dim=0)
 
     @torch.no_grad()
     def encode_first_stage_with_noise(self, x, noise=None):
@@ -102,5 +112,6 @@ class DiffusionEngine(nn.Module):
     @torch.no_grad()
     def encode_first_stage(self, x):
         from hi3d_hip.runtime_vae import run_chunks
-        outs = run_chunks(lambda lo, hi: self.first_stage_model.encode(x[lo:hi]), self._chunks(x.shape[0]), x.device)
+        outs = run_chunks(lambda lo, hi: self.first_stage_model.encode(x[lo:hi]), self._chunks(x.shape[0]), x.device,
+                          prepare=lambda: self._build_first_stage_runtime(x.device, "encode"))
         return self.scale_factor * torch.cat(outs, dim=0)

@@ -157,6 +157,9 @@ int hi3d_debug_gemm_launch_info(const hi3d_gemm_desc* d, void* params_out, int32
 int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* stream, void* params_out, int32_t* info);
 /* 1 if hi3d_gemm_bf16(d, stream) will fill d->gn_partial, 0 if that launch cannot (nothing is launched) */
 int hi3d_gemm_gn_partial_supported(const hi3d_gemm_desc* d, void* stream);
+/* ... or ask AFTER the launch: 1 when the last hi3d_gemm_bf16 call of the calling host thread filled gn_partial (one pass through
+ * the dispatch instead of two; what hi3d_hip/ops.py does).                                                                     */
+int hi3d_gemm_last_gn_fused(void);
 
 /* ------------------------------------------------------------------------ */
 /* Attention                                                                 */

@@ -79,6 +79,21 @@ def test_chunks_on_two_streams_equal_one_stream(dev, monkeypatch):
             synth.fill_module_(fresh, fx["weight_seed"], prefix=fx["key_prefix"])
             eng.first_stage_model = fresh.to(dev)
             assert torch.equal(eng.decode_first_stage(z), ref), (name, "first call", rep)
+        # ... and with a RAGGED last chunk (5 frames, 2 per call: 2 + 2 + 1) as the first call of a fresh model, the odd chunk on a
+        # side stream when there are three: per-stream scratch grown for another chunk size, runtime built before the fork
+        eng.en_and_decode_n_samples_a_time = 2
+        monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
+        ref2 = eng.decode_first_stage(z[:5])
+        assert torch.equal(ref2, ref[:5])                       # (the decoder is per frame: the chunking does not change a bit)
+        for ns in (3, 2):
+            monkeypatch.setattr(runtime_vae, "VAE_STREAMS", ns)
+            junk = torch.full((64 << 20,), float("nan"), device=dev)
+            del junk
+            fresh = AutoencoderKL(embed_dim=4, ddconfig=fx["ddconfig"])
+            synth.fill_module_(fresh, fx["weight_seed"], prefix=fx["key_prefix"])
+            eng.first_stage_model = fresh.to(dev)
+            assert torch.equal(eng.decode_first_stage(z[:5]), ref2), (name, "ragged first call", ns)
+        eng.en_and_decode_n_samples_a_time = 1
         if name == "vae_tiny":                                  # the encoder's chunk loop (posterior .sample(): same noise order)
             x = ref.clamp(-1, 1)
             monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
