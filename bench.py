@@ -172,40 +172,44 @@ def main():
         # process if the leg does not come back (a stuck collective cannot be interrupted from Python)
         import threading
 
+        LEGS = ("clip_parallel", "clip_parallel_32views", "vae_decode_sharded", "clip_parallel_cfg1_overlap")
+        state = {"leg": LEGS[0], "disarm": (lambda: None)}
+
         def _bail():
-            disarm()
-            if rank == 0:
-                out["clip_parallel"] = {"error": "timed out (watchdog); headline numbers above are unaffected"}
+            state["disarm"]()
+            if rank == 0:      # (only the leg that did not come back is marked: the finished ones keep their results)
+                out[state["leg"]] = {"error": "timed out (watchdog); the headline numbers and the finished legs are unaffected"}
                 print(json.dumps(out), flush=True)
             os._exit(0)
-        # ... and if the process itself dies in there (an abort inside the collective library), a detached helper prints it
-        disarm = lambda: None                            # noqa: E731
-        if rank == 0:
-            try:
-                disarm = guard_line(json.dumps(dict(out, clip_parallel={"error": "process died inside the optional leg; headline "
-                                                                                 "numbers above are unaffected"})))
-            except Exception as e:                        # noqa: BLE001 -- the guard is insurance, never a reason to fail
-                log(f"[bench] line guard not armed: {type(e).__name__}: {e}")
-        wd = threading.Timer(max(240.0, 120.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
-        wd.daemon = True
-        wd.start()
+
+        def entering(leg):
+            """Before each leg: the watchdog restarts with that leg's name, and the detached helper that prints the line if THIS
+            process dies (an abort inside the collective library) is re-armed with everything measured so far."""
+            state["leg"] = leg
+            state["disarm"]()
+            state["disarm"] = lambda: None
+            if state.get("wd") is not None:
+                state["wd"].cancel()
+            if rank == 0:
+                try:
+                    state["disarm"] = guard_line(json.dumps(dict(out, **{leg: {"error": "process died inside this optional leg; the "
+                                                                                 "headline numbers and the finished legs are unaffected"}})))
+                except Exception as e:                    # noqa: BLE001 -- the guard is insurance, never a reason to fail
+                    log(f"[bench] line guard not armed: {type(e).__name__}: {e}")
+            state["wd"] = threading.Timer(max(240.0, 120.0 * (a.steps + a.warmup + 2) * ms_per_step / 1e3), _bail)
+            state["wd"].daemon = True
+            state["wd"].start()
+
+        entering("clip_parallel")
         lat = 64 if stage == 1 else 128
         try:
             out["clip_parallel"] = clip_parallel_leg(a, unet, sampler.guider, stage, a.views, lat, dev, world, ms_per_step)
         except Exception as e:
             out["clip_parallel"] = {"error": f"{type(e).__name__}: {e}"}
-        # the other mapping of the same clip: cfg 1 x sp N -- every rank holds BOTH CFG halves of its frames and runs them as two
-        # chains on two streams with a communicator each, so one half's exchange overlaps the other half's compute (the cfg 2
-        # mapping above has no independent work on a rank to overlap with); more, smaller collectives, no idle CUs while waiting
-        if "error" not in out["clip_parallel"]:
-            try:
-                out["clip_parallel_cfg1_overlap"] = clip_parallel_leg(a, unet, sampler.guider, stage, a.views, lat, dev, world, ms_per_step,
-                                                                      steps=max(2, a.steps // 2), cfg_split=1, overlap=True)
-            except Exception as e:
-                out["clip_parallel_cfg1_overlap"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE config 4: "Stage-2 32 views @ 1024^2, view-parallel shard over 8 x MI355X with RCCL all-gather at VAE decode":
         # the 32-view clip on all GPUs (CFG pair x frame<->space groups), and the sharded decode of its frames + the all-gather
         if "error" not in out["clip_parallel"] and stage == 2 and a.views == 16:
+            entering("clip_parallel_32views")
             try:
                 from sgm.modules.diffusionmodules.guiders import LinearPredictionGuider
                 g32 = LinearPredictionGuider(max_scale=2.0, num_frames=32, min_scale=1.0)
@@ -213,16 +217,26 @@ def main():
                                                                  steps=max(2, a.steps // 2))
             except Exception as e:
                 out["clip_parallel_32views"] = {"error": f"{type(e).__name__}: {e}"}
-        if not any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_cfg1_overlap", "clip_parallel_32views")):
-            del unet, sampler
-            unet = sampler = None
+        if not any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_32views")):
+            entering("vae_decode_sharded")
             torch.cuda.empty_cache()
             try:
                 out["vae_decode_sharded"] = vae_sharded_leg(a, 32 if (stage == 2 and a.views == 16) else a.views, lat, dev, world)
             except Exception as e:
                 out["vae_decode_sharded"] = {"error": f"{type(e).__name__}: {e}"}
-        wd.cancel()
-        disarm()
+        # LAST (it has never run over RCCL: whatever it does, the legs above are already in the line):
+        # the other mapping of the same clip: cfg 1 x sp N -- every rank holds BOTH CFG halves of its frames and runs them as two
+        # chains on two streams with a communicator each, so one half's exchange overlaps the other half's compute (the cfg 2
+        # mapping above has no independent work on a rank to overlap with); more, smaller collectives, no idle CUs while waiting
+        if not any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_32views", "vae_decode_sharded")):
+            entering("clip_parallel_cfg1_overlap")
+            try:
+                out["clip_parallel_cfg1_overlap"] = clip_parallel_leg(a, unet, sampler.guider, stage, a.views, lat, dev, world, ms_per_step,
+                                                                      steps=max(2, a.steps // 2), cfg_split=1, overlap=True)
+            except Exception as e:
+                out["clip_parallel_cfg1_overlap"] = {"error": f"{type(e).__name__}: {e}"}
+        state["wd"].cancel()
+        state["disarm"]()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

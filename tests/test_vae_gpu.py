@@ -84,7 +84,9 @@ def test_chunks_on_two_streams_equal_one_stream(dev, monkeypatch):
         eng.en_and_decode_n_samples_a_time = 2
         monkeypatch.setattr(runtime_vae, "VAE_STREAMS", 1)
         ref2 = eng.decode_first_stage(z[:5])
-        assert torch.equal(ref2, ref[:5])                       # (the decoder is per frame: the chunking does not change a bit)
+        # (the decoder is per frame, but a two-frame call has other M -- other tile variants / split-K choices than a one-frame
+        # call: equal up to accumulation order, not bit for bit)
+        assert ((ref2.float() - ref[:5].float()).abs().max() / ref.float().abs().max()).item() < 2e-2
         for ns in (3, 2):
             monkeypatch.setattr(runtime_vae, "VAE_STREAMS", ns)
             junk = torch.full((64 << 20,), float("nan"), device=dev)
