@@ -2,7 +2,7 @@
 """Build profiles/traffic_<cfg>.json (HBM bytes per launch of the dominant kernels) from the two
 pmc_traffic.py summaries of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.
 
-usage: make_traffic_json.py FETCH.csv WRITE.csv out.json
+usage: make_traffic_json.py FETCH.csv WRITE.csv out.json [layernorm rows per launch = 262144]
 
 FETCH_SIZE is doubled: on gfx950 it counts half of the bytes of 16 B/lane streams (see
 MI355X_MICROARCH.md; calibrated here on the C = 320 LayerNorm kernel, which reads 327,680 KB per launch at the
@@ -45,11 +45,15 @@ def main():
                       "every profiled launch belongs to a step; FETCH_SIZE doubled (gfx950 half-count for 16 B/lane streams, "
                       "calibrated on layernorm)",
         }
-    # calibration: the C = 320 LayerNorm reads 524288 x 320 bf16 = 327,680 KB per launch at the 128^2 level
+    # calibration: the C = 320 LayerNorm reads ln_rows x 320 bf16 per launch at the 128^2 level -- ln_rows = 262144 in the default
+    # two-stream step (half-batch launches; round 4's json carried the full-batch 327,680 KB here by mistake), 524288 with
+    # HI3D_TWO_STREAM=0; optional 4th argument
+    ln_rows = int(sys.argv[4]) if len(sys.argv) > 4 else 262144
     cal = [v for k, v in fetch.items() if k.startswith("layernorm_packed_kernel<8>") or k.startswith("layernorm_kernel<1>")]
     if cal:
-        res["calibration"] = {"layernorm_C320_fetch_KB_per_launch_reported": sum(c[1] for c in cal) / sum(c[0] for c in cal),
-                              "bytes_actually_read_KB": 327680}
+        rep = sum(c[1] for c in cal) / sum(c[0] for c in cal)
+        res["calibration"] = {"layernorm_C320_fetch_KB_per_launch_reported": rep, "KB_actually_read_per_launch": ln_rows * 640 // 1024,
+                              "x2_corrected_over_actual": round(2.0 * rep / (ln_rows * 640 / 1024), 4)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
