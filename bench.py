@@ -60,6 +60,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# The contract is ONE JSON line on stdout.  Libraries write to fd 1 behind Python's back -- RCCL prints a five-line version banner
+# there when the first communicator is made (seen in the one-rank dry run of the multi-GPU legs) -- so main() takes the real
+# stdout aside and points fd 1 at stderr for the rest of the process; emit() is the only writer of the real one.
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def guard_line(line):
     """Insurance for the ONE JSON line while an optional leg runs that could take the process down hard (a collective library
     aborting cannot be caught in Python): a detached helper that inherits stdout blocks on a pipe whose write end only THIS
@@ -71,6 +91,7 @@ def guard_line(line):
             "b=os.read(int(sys.argv[1]),1)\n"
             "if b==b'':\n    sys.stdout.write(sys.argv[2]+'\\n'); sys.stdout.flush()\n")
     subprocess.Popen([sys.executable, "-c", code, str(r), line], stdin=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                     stdout=_REAL_STDOUT,          # (None before claim_stdout(): inherit fd 1)
                      start_new_session=True, pass_fds=(r,))
     os.close(r)
     state = {"armed": True}
@@ -110,6 +131,7 @@ def main():
     ap.add_argument("--no-clip-parallel", action="store_true",
                     help="N > 1: skip the extra leg that runs ONE clip over all GPUs (CFG split x frame<->space all-to-all, RCCL)")
     a = ap.parse_args()
+    claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +151,7 @@ def main():
     if a.config == "vae":
         res = bench_vae(a, rank, world, dev, use_dist, a.steps, a.warmup)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(json.dumps(res))
         if use_dist:
             torch.distributed.destroy_process_group()
         return
@@ -179,7 +201,7 @@ def main():
             state["disarm"]()
             if rank == 0:      # (only the leg that did not come back is marked: the finished ones keep their results)
                 out[state["leg"]] = {"error": "timed out (watchdog); the headline numbers and the finished legs are unaffected"}
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
             os._exit(0)
 
         def entering(leg):
@@ -238,7 +260,7 @@ def main():
         state["wd"].cancel()
         state["disarm"]()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if use_dist:
         if any("error" in out.get(k, {}) for k in ("clip_parallel", "clip_parallel_cfg1_overlap", "clip_parallel_32views", "vae_decode_sharded")):
             sys.stdout.flush()

@@ -61,7 +61,7 @@ def unet_inputs(cfg, T, hw, seed):
     return synth.synth_unet_inputs(cfg, T, hw, seed)
 
 
-def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None, compact=False):
+def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None, compact=False, halves=False):
     """compact: the inputs are NOT stored (they are re-drawn from `input_seed` by
     synth.synth_unet_inputs, pinned by `input_probe`) and the output is stored in fp16 -- for the
     full-size stage-2 forward, whose fp32 input alone is 36 MB."""
@@ -71,10 +71,23 @@ def gen_unet(name, cfg, T, hw, wseed=1, iseed=0, ioi=None, compact=False):
     if ioi is not None:
         inp["image_only_indicator"] = ioi
     with torch.no_grad():
-        out = m(inp["x"], inp["timesteps"], context=inp["context"], y=inp["y"], time_context=None,
-                num_video_frames=T, image_only_indicator=inp["image_only_indicator"])
+        if halves:
+            # the two clips of the CFG-doubled batch one after the other (they never mix inside the network: every rearrange
+            # keeps b outermost) -- halves the reference's peak memory: BASELINE config 4 at its real size
+            # (2 x 32 frames, latent 128 x 128) needs ~90 GB in one call, ~45 GB this way (the build container has 62)
+            outs = []
+            for b in (0, 1):
+                fs = slice(b * T, (b + 1) * T)
+                outs.append(m(inp["x"][fs], inp["timesteps"][fs], context=inp["context"][b:b + 1], y=inp["y"][b:b + 1], time_context=None,
+                              num_video_frames=T, image_only_indicator=inp["image_only_indicator"][b:b + 1]))
+                print(f"{name}: clip {b} done ({time.time() - t0:.0f}s)", flush=True)
+            out = torch.cat(outs, 0)
+            del outs
+        else:
+            out = m(inp["x"], inp["timesteps"], context=inp["context"], y=inp["y"], time_context=None,
+                    num_video_frames=T, image_only_indicator=inp["image_only_indicator"])
     sd = m.state_dict()
-    fx = dict(kind="unet", cfg=cfg, T=T, weight_seed=wseed, key_prefix=UNET_PREFIX, inputs=inp, output=out,
+    fx = dict(kind="unet", cfg=cfg, T=T, two_calls=bool(halves), weight_seed=wseed, key_prefix=UNET_PREFIX, inputs=inp, output=out,
               n_tensors=len(sd), shapes_sha256=shapes_digest(sd), shapes={k: tuple(v.shape) for k, v in sd.items()},
               probe={k: sd[k].flatten()[:4].clone() for k in list(sd)[:3]})
     if compact:
@@ -331,6 +344,9 @@ def main():
         jobs["vae_full_512"] = lambda: gen_vae("vae_full_512", 128, 1, 64, iseed=5, compact=True)
         jobs["vae_full_1024"] = lambda: gen_vae("vae_full_1024", 128, 1, 128, iseed=6, compact=True)
         jobs["unet_s2_full"] = lambda: gen_unet("unet_s2_full", unet_cfg(2), T=16, hw=128, iseed=8, compact=True)
+        # BASELINE config 4 at its REAL size: 2 x 32 views, latent 128 x 128 (M = 1,048,576 token rows), the reference's own classes,
+        # one clip per call (~20 min per clip on 8 cores, ~45 GB peak)
+        jobs["unet_s2_full_t32"] = lambda: gen_unet("unet_s2_full_t32", unet_cfg(2), T=32, hw=128, iseed=88, compact=True, halves=True)
     for k, fn in jobs.items():
         if a.only is None or a.only == k:
             fn()

@@ -28,6 +28,7 @@ ROW_TESTS = [
         "test_unet_gpu.py::test_unet_full_size_stage1_matches_reference_golden",
         "test_at_size_gpu.py::test_unet_full_size_stage2_matches_reference_golden[bf16]",
         "test_at_size_gpu.py::test_unet_full_width_32_views_matches_reference_golden",
+        "test_at_size_gpu.py::test_unet_config4_full_size_matches_reference_golden",
         "test_unet_gpu.py::test_unet_vs_oracle_other_shape",
         "test_unet_gpu.py::test_unet_32_views_vs_oracle"]),
     ("a16 decode_first_stage / Decoder", [

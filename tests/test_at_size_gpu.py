@@ -216,6 +216,34 @@ def test_unet_full_size_stage2_matches_reference_golden(dev, attn, monkeypatch):
     assert rel < tol and c > cmin
 
 
+def test_unet_config4_full_size_matches_reference_golden(dev):
+    """BASELINE config 4 at its REAL size against the REFERENCE (until round 5 this size had kernels vs fp32
+    and the network vs itself only): the full-width stage-2 VideoUNet on the CFG pair of a 32-view clip -- 64 frames, latent
+    128 x 128, 1,048,576 token rows, 16384-token spatial attention at B = 64, temporal attention / Conv3d / 3-D GroupNorm over 32
+    frames -- in ONE forward on the GPU (the product's batch of 64), against the reference's own VideoUNet run on the CPU one
+    clip per call (the two clips never mix inside the network; 90 GB in one call, 45 GB this way; oracle/gen_golden.py
+    `unet_s2_full_t32`, ~40 min).  Same tolerance as the 16-view forward: 4e-2 of the output range, cosine >= 0.9995."""
+    from hi3d_hip import synth
+    if not os.path.exists(os.path.join(GOLD, "unet_s2_full_t32.pt")):
+        pytest.skip("unet_s2_full_t32.pt not generated")
+    fx = load("unet_s2_full_t32")
+    T, hw = fx["T"], fx["hw"]
+    assert (T, hw) == (32, 128) and fx.get("two_calls")
+    inp = synth.synth_unet_inputs(fx["cfg"], T, hw, fx["input_seed"])
+    x, pr = inp["x"], fx["input_probe"]
+    assert torch.equal(x.flatten()[:16], pr["head"]) and abs(float(x.double().sum()) - pr["sum"]) < 1e-6 * pr["abs_sum"], \
+        "seeded inputs are not the ones the golden was generated from"
+    m = _build_unet(fx, dev)
+    out = m(x.to(dev), inp["timesteps"].to(dev), context=inp["context"].to(dev), y=inp["y"].to(dev),
+            num_video_frames=T, image_only_indicator=inp["image_only_indicator"].to(dev))
+    ref = fx["output"].float()
+    assert tuple(out.shape) == tuple(ref.shape) == (64, 4, 128, 128)
+    rel, c = relerr(out, ref), cos(out, ref)
+    relh = [relerr(out[b * T:(b + 1) * T], ref[b * T:(b + 1) * T]) for b in (0, 1)]
+    print(f"unet_s2_full_t32 (config 4, 64 frames @ 128^2): rel {rel:.4f} cos {c:.6f}; per clip {relh[0]:.4f} / {relh[1]:.4f}")
+    assert rel < 4e-2 and c > 0.9995
+
+
 @pytest.mark.parametrize("name", ["unet_s2_lat16_t32", "unet_s2_lat64_t32"])
 def test_unet_full_width_32_views_matches_reference_golden(dev, name):
     """BASELINE config 4 (32 views): the full-width stage-2 UNet (320 .. 1280 channels) at T = 32 -- CFG batch 64 -- on
