@@ -36,10 +36,19 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTI
   python $R/tools/pmc_sum.py /tmp/pmc_sq$i > $O/s2_pmc_sq$i.csv 2>&1
   rm -rf /tmp/pmc_sq$i
 done
+# BASELINE config 5 (fp8 attention, both products): the same two SQ sets -- MFMA-busy against VALU-active of attn_d64_fp8_kernel
+# ("for fp8 the P-pack / quantise VALU is now the bound -- show it in PMC")
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  HI3D_STEP_GRAPH=0 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_f8sq$i -o run --output-format csv -- python $R/bench.py --attn fp8 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-legs > $O/pmc_fp8_sq$i.log 2>&1
+  python $R/tools/pmc_sum.py /tmp/pmc_f8sq$i > $O/s2_fp8_pmc_sq$i.csv 2>&1
+  rm -rf /tmp/pmc_f8sq$i
+done
 if [ -n "$LIGHT" ]; then     # (the per-shape conv traffic and the GEMM variant sweep only change when gemm.hip does)
   python $R/tools/make_traffic_json.py $O/s2_pmc_FETCH_SIZE.csv $O/s2_pmc_WRITE_SIZE.csv $O/traffic_s2.json
   cat $O/s2_bench.json | cut -c1-900; head -14 $O/s2_kernel_stats.csv; head -8 $O/s2_pmc_FETCH_SIZE.csv
-  head -8 $O/s2_pmc_WRITE_SIZE.csv; head -14 $O/s2_pmc_sq1.csv; head -8 $O/s2_pmc_sq2.csv
+  head -8 $O/s2_pmc_WRITE_SIZE.csv; head -14 $O/s2_pmc_sq1.csv; head -8 $O/s2_pmc_sq2.csv; grep -i "attn" $O/s2_fp8_pmc_sq1.csv $O/s2_fp8_pmc_sq2.csv
   exit 0
 fi
 # conv3x3 traffic per shape: FETCH_SIZE counts Infinity-Cache hits too, so the weights -- re-streamed
