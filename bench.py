@@ -174,13 +174,23 @@ def main():
         if not a.no_traffic and not a.no_profile and "roofline" in out:
             gc_ = __import__("gc"); gc_.collect(); torch.cuda.empty_cache()
             two = "two HIP streams" in out["config"].get("streams", "")
+            # (the headline and the legs are measured at this point -- a helper prints the line as it stands if this
+            # process is killed while the two PMC child runs are under way, e.g. by a time-limited driver)
+            try:
+                disarm = guard_line(json.dumps(dict(out, note="printed by the line guard: the process ended during the live traffic passes")))
+            except Exception:                           # noqa: BLE001
+                disarm = lambda: None
             try:
                 live, src = measure_traffic_live(ln_rows=2 * a.views * 128 * 128 // (2 if two else 1))
             except Exception as e:                      # noqa: BLE001 -- never lose the line to the optional measurement
                 live, src = None, f"{type(e).__name__}: {e}"
+            disarm()
             kern = out["roofline"]["kernel"]
             if live and kern in live:
                 out["roofline"]["traffic"] = live[kern]["bytes_per_launch"]
+                ab = out["roofline"].get("algorithmic_bytes_per_launch")
+                if ab:
+                    out["roofline"]["traffic_over_algorithmic"] = round(live[kern]["bytes_per_launch"] / ab, 3)
                 out["roofline"]["traffic_source"] = src
                 out["roofline"]["traffic_detail"] = live
             else:
@@ -289,14 +299,14 @@ def measure_traffic_live(ln_rows):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="hi3d_pmc_", dir="/tmp")
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-        env.update(HI3D_STEP_GRAPH="0", TMPDIR="/tmp")
+        env.update(HI3D_STEP_GRAPH="0", HI3D_BENCH_PARITY="0", TMPDIR="/tmp")
         cmd = [rp, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "run", "--output-format", "csv", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-legs", "--no-traffic"]
         t0 = time.time()
         try:
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                rc = pr.wait(timeout=300)
+                rc = pr.wait(timeout=180)
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, signal.SIGKILL)            # (the group THIS call started, nothing else)
                 pr.wait()
@@ -420,7 +430,7 @@ def run_legs(a, rank, world, dev):
             o, u, sm, _ = unet_bench(a, kw["stage"], kw["T"], kw["attn"], rank, world, dev, False, a.leg_steps, 3, profile=True, cpu=False)
             del u, sm
             legs[name] = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "step_roofline",
-                                            "roofline", "kernels_ms_per_step") if k in o}
+                                            "roofline", "kernels_ms_per_step", "parity_checked", "parity") if k in o}
             legs[name]["workload"] = o["config"]["workload"]
         except Exception as e:                      # noqa: BLE001
             legs[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -453,13 +463,26 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
     with torch.device(dev):
         unet = VideoUNet(**cfg)
     ParamTree.skip_init = False
-    synth.fill_module_on_device_(unet, seed=1, prefix="model.diffusion_model.")
+    # parity of the timed region itself: where a reference-class fixture of THIS configuration exists
+    # (tests/golden/sampler_s*_full_*.pt: the reference's EulerEDMSampler.step_call on the CPU, oracle/gen_golden.py), rank 0
+    # carries the fixture's weights (hi3d_hip.synth CPU stream -- drawn on the host, ~20 s) and starts from the fixture's seeded
+    # clip, and the first timed steps are compared with the reference after the clock has stopped.  HI3D_BENCH_PARITY=0 skips it.
+    parity_fx = None
+    fx_name = {(2, 16): "sampler_s2_full_3step", (1, 16): "sampler_s1_full_25step"}.get((stage, T))
+    fx_path = os.path.join(ROOT, "tests", "golden", f"{fx_name}.pt")
+    if fx_name and attn == "bf16" and rank == 0 and os.path.exists(fx_path) and os.environ.get("HI3D_BENCH_PARITY", "1") != "0":
+        parity_fx = torch.load(fx_path, weights_only=False)
+        assert (parity_fx["stage"], parity_fx["T"], parity_fx["hw"], parity_fx["steps"]) == (stage, T, lat, 25)
+    if parity_fx is not None:
+        synth.fill_module_(unet, parity_fx["weight_seed"], prefix=parity_fx["key_prefix"])
+    else:
+        synth.fill_module_on_device_(unet, seed=1, prefix="model.diffusion_model.")
     cpu_sd = None
     if cpu:
         cpu_sd = {"model.diffusion_model." + k: v.float().cpu() for k, v in unet.state_dict().items()}
     model = OpenAIWrapper(unet)
     unet.runtime(dev)                      # one-time weight re-layout
-    log(f"[bench] rank {rank}: model built + packed in {time.time() - t0:.1f}s")
+    log(f"[bench] rank {rank}: model built + packed in {time.time() - t0:.1f}s" + (f" (weights and clip of {fx_name}.pt)" if parity_fx else ""))
 
     den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
     sampler = EulerEDMSampler(
@@ -468,7 +491,12 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                                "params": {"sigma_max": 700.0}},
         guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
                        "params": {"num_frames": T, "max_scale": 2.5 if stage == 1 else 2.0, "min_scale": 1.0}})
-    x0, c, uc = synth.synth_conditioning(T, lat, lat, stage=stage, seed=rank)    # a different clip per rank
+    # a different clip per rank (rank 0: the fixture's clip when the timed steps are parity-checked)
+    x0, c, uc = synth.synth_conditioning(T, lat, lat, stage=stage, seed=parity_fx["input_seed"] if parity_fx else rank)
+    if parity_fx is not None:
+        pr = parity_fx["x0_probe"]
+        if not (torch.equal(x0.flatten()[:16], pr["head"]) and abs(float(x0.double().sum()) - pr["sum"]) < 1e-6 * pr["abs_sum"]):
+            raise SystemExit("parity fixture: the seeded clip is not the one the reference ran")
     c = {k: v.to(dev) for k, v in c.items()}
     uc = {k: v.to(dev) for k, v in uc.items()}
     extra = dict(image_only_indicator=torch.zeros(2, T, device=dev), num_video_frames=T)
@@ -478,6 +506,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
 
     x, s_in, sigmas, num_sigmas, cond, ucond = sampler.prepare_sampling_loop(x0.to(dev), c, uc)
     n_sched = num_sigmas - 1
+    x_start = x.clone()
 
     def step(i, x):
         return sampler.step_call(denoiser, x, i % n_sched, s_in, sigmas, num_sigmas, cond, ucond)
@@ -488,14 +517,21 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
 
     for i in range(max(warmup, 3)):           # >= 3: the third fused step captures the HIP graph
         x = step(i, x)
+    # the timed steps are steps 0 .. K-1 of the schedule, from the prepared start state (the steps the parity fixture holds);
+    # the states of the first three are kept by reference (step() returns a fresh tensor): nothing is added to the timed region
+    x, kept = x_start, []
     barrier(); torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        x = step(i, x)
+    for i in range(steps):
+        x_next = step(i, x)
+        if i < 3:
+            kept.append((x, x_next))
+        x = x_next
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t_start
     if not torch.isfinite(x).all():
         raise SystemExit("non-finite latents after the timed steps")
+    parity = check_timed_steps(parity_fx, fx_name, kept, sigmas) if parity_fx is not None else None
     steppers = list(unet.runtime(dev).steppers.values())
     graphed = bool(steppers) and steppers[0].graph is not None
     two_stream = bool(getattr(unet.runtime(dev), "last_forward_two_stream", False))
@@ -504,7 +540,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
     if prof is not None:
         ops.PROFILER = prof
         t_p = time.perf_counter()
-        for i in range(warmup, warmup + steps):
+        for i in range(steps, 2 * steps):
             x = step(i, x)
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t_p) / steps * 1e3
@@ -530,6 +566,10 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
                    "streams": "two HIP streams inside the step: the unconditional / conditional halves of the batch through the "
                               "two largest resolution levels side by side (HI3D_TWO_STREAM=auto)" if two_stream else "one"},
     }
+    out["parity_checked"] = parity is not None
+    if parity is not None:
+        parity["launch_mode"] = ("HIP-graph replay" if graphed else "eager launches") + (", two HIP streams" if two_stream else "")
+        out["parity"] = parity
     step_tf = STEP_TFLOP[stage] * (T / 16.0)
     summ = prof.summary() if prof is not None else None
     # executed work per step: what the kernels of this step actually compute (per-launch count of the profiled steps)
@@ -562,6 +602,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         at = summ.get("attn_d64", summ.get("attn_d64_fp8qk", summ.get("attn_d64_fp8", dict(ms=0.0, flops=0.0, launches=1))))
         dom_is_gemm = g_ms >= at["ms"]
         k_ms, k_fl, k_n = (g_ms, g_fl, g_n) if dom_is_gemm else (at["ms"], at["flops"], at["launches"])
+        k_by = sum(d["bytes"] for d in g) if dom_is_gemm else at.get("bytes", 0.0)
         ach = k_fl / (k_ms * 1e-3) / 1e12
         # HBM traffic per launch of that kernel from rocprofv3 PMC passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py);
@@ -573,6 +614,9 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if dom_is_gemm else "attn_d64_kernel",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           # algorithmic bytes per launch (every operand element once: ops.gemm's count), beside the measured traffic
+                           "algorithmic_bytes_per_launch": int(k_by / k_n),
+                           "traffic_over_algorithmic": round(traffic / (k_by / k_n), 3) if traffic and k_by else None,
                            "launches_per_step": k_n // steps, "avg_launch_ms": round(k_ms / k_n, 4),
                            "share_of_step": round(k_ms / steps / ms_per_step, 3),
                            "timing": f"HIP events around every launch over the {steps} steps after the timed region "
@@ -606,8 +650,50 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         step_flops_exec = None
 
     if cpu_sd is not None:
-        out["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
+        port = cpu_baseline(cpu_sd, cfg, stage, unet, dev, step_flops_exec, step_tf)
+        out["cpu_baseline"] = port
+        if parity_fx is not None and parity_fx.get("ref_step_seconds"):
+            # the reference's OWN classes on this exact configuration: their wall time per denoise step was
+            # recorded when the parity fixture was generated (oracle/gen_golden.py, build container: the Python reference cannot
+            # travel to the GPU box); the port timed live on THIS host's cores stays beside it
+            ss, h = parity_fx["ref_step_seconds"], parity_fx["ref_host"]
+            mean_s = sum(ss) / len(ss)
+            out["cpu_baseline"] = {
+                "value": round(1.0 / mean_s, 6), "unit": "steps/s", "cores": h["threads"], "kind": "reference",
+                "seconds_per_step": [round(t, 1) for t in ss],
+                "sample": f"{len(ss)} full denoise steps of THIS configuration (CFG batch {2 * T} at latent {lat}x{lat}, full width) through "
+                          "the reference's EulerEDMSampler.step_call + LinearPredictionGuider + Denoiser + VideoUNet, fp32, no extrapolation; "
+                          f"recorded by oracle/gen_golden.py in tests/golden/{fx_name}.pt on {h['where']}: {h['cpu']}, {h['threads']} torch "
+                          f"threads on {h['cores']} cores, torch {h['torch']} (the Python reference does not travel to the GPU box)",
+                "host": h, "port_on_this_host": port}
     return out, unet, sampler, ms_per_step
+
+
+PARITY_TOL, PARITY_COS = 2.5e-2, 0.999
+
+
+def check_timed_steps(fx, fx_name, kept, sigmas):
+    """The first timed steps against the reference-class fixture (same bound as tests/test_timed_path_gpu.py): the guided
+    denoised estimate D_i = (x_{i+1} - x_i s_{i+1}/s_i) / (1 - s_{i+1}/s_i) of every kept step vs the reference's
+    EDMSampler.denoise output -- the state itself hides the network at sigma ~ 500 (|x| ~ 2800, |D| ~ 5).  Exits non-zero on a
+    miss: a throughput number from a step that computes something else is not a measurement."""
+    if not torch.allclose(sigmas.float().cpu(), fx["sigmas"], rtol=1e-6, atol=0):
+        raise SystemExit("parity fixture: sigma schedule differs from the reference's")
+    per_step = []
+    for i, (x, x_next) in enumerate(kept[:fx["n_run"]]):
+        r = (sigmas[i + 1] / sigmas[i]).double()
+        D = ((x_next.double() - x.double() * r) / (1.0 - r)).float().cpu()
+        ref = fx["denoised_f16"][i].float()
+        rel = ((D - ref).abs().max() / ref.abs().max()).item()
+        cs = torch.nn.functional.cosine_similarity(D.flatten(), ref.flatten(), dim=0).item()
+        per_step.append({"step": i, "denoised_rel": round(rel, 5), "cos": round(cs, 6)})
+        log(f"[bench] parity of timed step {i} vs the reference classes ({fx_name}.pt): denoised rel {rel:.4f} cos {cs:.6f}")
+        if not (rel < PARITY_TOL and cs > PARITY_COS):
+            raise SystemExit(f"PARITY FAILURE in the timed region: step {i} denoised rel {rel:.4f} cos {cs:.6f} "
+                             f"(bounds {PARITY_TOL} / {PARITY_COS}) vs tests/golden/{fx_name}.pt")
+    return {"fixture": f"tests/golden/{fx_name}.pt (the reference's EulerEDMSampler.step_call + guider + denoiser + VideoUNet, fp32 CPU)",
+            "compared": "guided denoised estimate of each of the first timed steps, recovered from the two fp32 states around it",
+            "steps": per_step, "tolerance": {"denoised_rel": PARITY_TOL, "cos": PARITY_COS}}
 
 
 def clip_parallel_leg(a, unet, guider, stage, T, lat, dev, world, replica_ms, steps=None, cfg_split=None, overlap=False):

@@ -961,6 +961,47 @@ extern "C" int hi3d_gemm_set_workspace_for_stream(void* ptr, int64_t bytes, void
   return HI3D_OK;
 }
 
+namespace {
+// The dispatch's A/B switches (HI3D_GEMM_TILE_N / _NO_NARROW / _VARIANT / _ABL / _GN / _SPLITK, HI3D_GN_FUSED_OFF), read from the
+// environment ONCE per process -- round 5 called getenv up to 7 times per launch, invisible under graph replay but paid ~750 times
+// per rank-step on the eager clip-parallel path.  A caller that changes one of them inside a running process
+// (the tests, tools/kbench.py sweeps) calls hi3d_gemm_reload_env() afterwards.
+struct GemmEnv {
+  int tile_n = 0;                   // HI3D_GEMM_TILE_N: 128 / 160, 0 = host heuristic
+  bool no_narrow = false;           // HI3D_GEMM_NO_NARROW set: no 128 x 32 tile for N <= 32
+  bool has_variant = false; int variant = 0;      // HI3D_GEMM_VARIANT
+  int abl = 0;                      // HI3D_GEMM_ABL (ablation bits of the epilogue study)
+  bool has_gn = false; int gn = 0;  // HI3D_GEMM_GN: column-group width of the tile raster
+  bool gn_fused_off = false;        // HI3D_GN_FUSED_OFF set
+  int splitk = -1;                  // HI3D_GEMM_SPLITK: 0 = never, S > 1 = force S, -1 = heuristic
+  void load() {
+    *this = GemmEnv{};
+    if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile_n = t; }
+    no_narrow = getenv("HI3D_GEMM_NO_NARROW") != nullptr;
+    if (const char* e = getenv("HI3D_GEMM_VARIANT")) { has_variant = true; variant = atoi(e); }
+    if (const char* e = getenv("HI3D_GEMM_ABL")) abl = atoi(e);
+    if (const char* e = getenv("HI3D_GEMM_GN")) { has_gn = true; gn = atoi(e); }
+    gn_fused_off = getenv("HI3D_GN_FUSED_OFF") != nullptr;
+    if (const char* e = getenv("HI3D_GEMM_SPLITK")) splitk = atoi(e);
+  }
+};
+GemmEnv g_env_storage;
+std::mutex g_env_mu;
+const GemmEnv& gemm_env() {
+  static const bool once = [] { std::lock_guard<std::mutex> lk(g_env_mu); g_env_storage.load(); return true; }();
+  (void)once;
+  return g_env_storage;
+}
+
+}  // namespace
+
+extern "C" int hi3d_gemm_reload_env(void) {
+  (void)gemm_env();                                  // (the first-use load happens-before this one)
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  g_env_storage.load();
+  return HI3D_OK;
+}
+
 extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->W || !d->out) HI3D_FAIL(HI3D_EINVAL, "gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) HI3D_FAIL(HI3D_EINVAL, "gemm: non-positive size");
@@ -969,6 +1010,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if (d->rows_per_group < 1) HI3D_FAIL(HI3D_EINVAL, "gemm: rows_per_group < 1");
   if (d->epi != HI3D_EPI_AFFINE && d->epi != HI3D_EPI_GEGLU) HI3D_FAIL(HI3D_EINVAL, "gemm: bad epi");
   if (((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->out) & 15) HI3D_FAIL(HI3D_EALIGN, "gemm: A/W/out not 16-byte aligned");
+  const GemmEnv& env = gemm_env();
   GemmParams p;
   p.A = (const char*)d->A; p.W = (const char*)d->W; p.bias = d->bias; p.rowvec = d->rowvec;
   p.R1 = (const unsigned short*)d->R1; p.R2 = (const unsigned short*)d->R2; p.a1 = d->a1; p.a2 = d->a2;
@@ -1029,11 +1071,11 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     // 160 suits every multiple of 320; otherwise pick the tile that wastes fewer columns
     const int w128 = (d->N + 127) / 128 * 128, w160 = (d->N + 159) / 160 * 160;
     tile = (w160 <= w128) ? 160 : 128;
-    if (const char* e = getenv("HI3D_GEMM_TILE_N")) { const int t = atoi(e); if (t == 128 || t == 160) tile = t; }
+    if (env.tile_n) tile = env.tile_n;
   }
   // N <= 32 (the 4-channel output convs: UNet out.2, VAE conv_out): a 128 x 32 tile -- those launches are all
   // A stream (M = 0.5-1 M rows, K = 1152-2880) and a 128-column tile spent 97 % of its MFMAs and W traffic on padding
-  if (d->tile_n == 0 && d->N <= 32 && d->epi == HI3D_EPI_AFFINE && !getenv("HI3D_GEMM_NO_NARROW")) tile = 32;
+  if (d->tile_n == 0 && d->N <= 32 && d->epi == HI3D_EPI_AFFINE && !env.no_narrow) tile = 32;
   if (tile != 128 && tile != 160 && tile != 32) HI3D_FAIL(HI3D_EINVAL, "gemm: tile_n must be 0, 32, 128 or 160");
   // tile height / ring depth: 0 = 128 rows, 2-stage ring, 2 blocks/CU (default: fastest at every
   // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
@@ -1064,7 +1106,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   } else if (d->N % 256 == 0 && wide_fits(256)) {
     variant = 8;
   }
-  if (const char* e = getenv("HI3D_GEMM_VARIANT")) variant = atoi(e);
+  if (env.has_variant) variant = env.variant;
   if (two && variant != 7) variant = 0;           // two-source A: built for the 128-row 2-stage tile and the 256 x 320 ping-pong tile
   // split-K: a long-K launch that leaves most of the chip's 512 block slots (256 CUs x 2 blocks of the 128-row tile) empty
   // -- M = 1-4 K rows: the 8x8 level of stage 1 ran at 370 TFLOP/s, every level does on the ranks of a clip-parallel job --
@@ -1075,7 +1117,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   if ((variant == 0 || variant == 2) && (tile == 128 || tile == 160) && d->epi == HI3D_EPI_AFFINE && d->K >= 2048 &&
       (long)d->M * d->N >= (1L << 18) && (((uintptr_t)d->out | (uintptr_t)d->R1 | (uintptr_t)d->R2) & 7) == 0) {
     int dev = -1;
-    static const int force = [] { const char* e = getenv("HI3D_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+    const int force = env.splitk;
     if (force != 0 && hipGetDevice(&dev) == hipSuccess && (ws = ws_for(dev, (hipStream_t)stream, g_capture == nullptr)) != nullptr) {
       const int taps = d->amode == HI3D_A_CONV3X3 ? p.ntap : d->amode == HI3D_A_CONVT3 ? 3 : 1;
       const int units = d->K / BK / taps;
@@ -1090,8 +1132,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   const int bm = (variant == 2 || variant >= 5) ? 256 : 128;
   p.nbm = (d->M + bm - 1) / bm;
   p.nbn = (d->N + tile - 1) / tile;
-  p.abl = 0;
-  if (const char* e = getenv("HI3D_GEMM_ABL")) p.abl = atoi(e);
+  p.abl = env.abl;
   // column-group raster for weight matrices well beyond one XCD's L2 (4 MB): groups whose W slice is <= 2 MB, at least 2 wide
   // (dense / GEGLU and the conv gathers alike; HI3D_GEMM_GN overrides: 0 = off)
   p.gn = 0;
@@ -1101,7 +1142,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
       long g = (2L << 20) / ((long)tile * d->K * 2);
       p.gn = (int)(g < 2 ? 2 : g);
     }
-    if (const char* e = getenv("HI3D_GEMM_GN")) p.gn = atoi(e);
+    if (env.has_gn) p.gn = env.gn;
   }
   hipStream_t s = (hipStream_t)stream;
   const int amode = two ? A_DENSE2 : d->amode;
@@ -1127,7 +1168,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // channel count whose groups are whole inside a lane's 4*NT columns
   if (d->gn_partial && (variant == 7 || variant == 8) && d->epi == HI3D_EPI_AFFINE && !d->R1 && !d->R2 && !d->a1 && !d->a2 &&
       !d->out_fp32 && d->M % 256 == 0 && d->N % tile == 0 && d->N % 32 == 0 && (!d->rowvec || d->rows_per_group % 256 == 0) &&
-      ((uintptr_t)d->gn_partial & 7) == 0 && !getenv("HI3D_GN_FUSED_OFF")) {
+      ((uintptr_t)d->gn_partial & 7) == 0 && !env.gn_fused_off) {
     const int lc = tile == 320 ? 40 : 32, cpg = d->N / 32;
     if (cpg == lc || cpg * 2 == lc || cpg * 4 == lc) { p.gn_part = d->gn_partial; g_gn_fused = 1; }
   }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhi3d_hip.so")
 
 EXPORTS = [
-    "hi3d_abi_version", "hi3d_last_error", "hi3d_gemm_bf16", "hi3d_gemm_set_workspace", "hi3d_gemm_set_workspace_for_stream", "hi3d_debug_gemm_launch_info", "hi3d_debug_gemm_launch_info_on", "hi3d_attn_d64", "hi3d_attn_d64_v", "hi3d_attn_d512",
+    "hi3d_abi_version", "hi3d_last_error", "hi3d_gemm_bf16", "hi3d_gemm_set_workspace", "hi3d_gemm_set_workspace_for_stream", "hi3d_gemm_reload_env", "hi3d_debug_gemm_launch_info", "hi3d_debug_gemm_launch_info_on", "hi3d_attn_d64", "hi3d_attn_d64_v", "hi3d_attn_d512",
     "hi3d_transpose_v", "hi3d_attn_temporal_d64", "hi3d_attn_fp8_workspace_bytes", "hi3d_attn_quant_qk", "hi3d_attn_d64_fp8qk", "hi3d_attn_fp8_v_workspace_bytes", "hi3d_attn_quant_v", "hi3d_attn_d64_fp8", "hi3d_gn_partial_blocks",
     "hi3d_gn_workspace_floats", "hi3d_groupnorm_silu", "hi3d_groupnorm_silu_cat2", "hi3d_groupnorm_silu_from_partials", "hi3d_gemm_gn_partial_supported", "hi3d_gemm_last_gn_fused", "hi3d_groupnorm_partial_sums", "hi3d_groupnorm_apply_sums", "hi3d_layernorm",
     "hi3d_concat_channels", "hi3d_timestep_embedding", "hi3d_silu_f32_to_bf16",
@@ -70,6 +70,7 @@ def load():
         "hi3d_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
         "hi3d_gemm_set_workspace": (C.c_int, [vp, i64]),
         "hi3d_gemm_set_workspace_for_stream": (C.c_int, [vp, i64, vp]),
+        "hi3d_gemm_reload_env": (C.c_int, []),
         "hi3d_debug_gemm_launch_info": (C.c_int, [C.POINTER(GemmDesc), vp, C.POINTER(C.c_int32)]),
         "hi3d_debug_gemm_launch_info_on": (C.c_int, [C.POINTER(GemmDesc), vp, vp, C.POINTER(C.c_int32)]),
         "hi3d_attn_d64": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),

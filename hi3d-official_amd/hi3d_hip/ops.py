@@ -189,6 +189,12 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     return out if gn is None else (out, gn_ws)
 
 
+def gemm_reload_env():
+    """The GEMM dispatch reads its HI3D_GEMM_* / HI3D_GN_FUSED_OFF switches from the environment once per process; call this
+    after changing one of them in a running process (tests, tools/kbench.py sweeps)."""
+    _lib.hi3d_gemm_reload_env()
+
+
 def transpose_v(v_view, B, H, S, ldv):
     """v_view: tensor whose data_ptr is V[b=0,s=0,h=0,d=0]; returns vt [B,H,64,S_pad]."""
     S_pad = (S + 63) // 64 * 64

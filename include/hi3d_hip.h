@@ -18,9 +18,19 @@
  *     failed launch.  Nothing throws across the ABI.
  *   - activations are channels-last "token" tensors [frames, H*W, C] in bf16
  *     (raw uint16 storage), statistics / accumulators fp32.
- *   - the library never allocates persistent device memory; workspaces are
- *     caller-owned.  All entry points are re-entrant and stateless, hence
- *     HIP-graph capturable.
+ *   - the library never allocates device memory; workspaces are caller-owned.
+ *     Every launch is a pure function of its arguments and HIP-graph
+ *     capturable.  The library is NOT stateless on the host side, and says
+ *     where: (1) a mutex-guarded per-(device, stream) registry of the split-K
+ *     scratch buffers the caller registered (hi3d_gemm_set_workspace*: the
+ *     buffers stay the caller's and must outlive the launches; hi3d_hip/ops.py
+ *     pins 96 MiB per stream that ever ran a GEMM, HI3D_GEMM_WS_MB); (2) per
+ *     host thread, the description of the last error and the "last GEMM launch
+ *     filled gn_partial" flag (hi3d_gemm_last_gn_fused); (3) the dispatch's
+ *     HI3D_* A/B switches, read from the environment once per process
+ *     (hi3d_gemm_reload_env re-reads them); (4) per kernel and device, a flag
+ *     that its dynamic-LDS limit has been raised.  Entry points are re-entrant
+ *     across host threads and streams.
  */
 #ifndef HI3D_HIP_H
 #define HI3D_HIP_H
@@ -158,8 +168,14 @@ int hi3d_debug_gemm_launch_info_on(const hi3d_gemm_desc* d, void* stream, void* 
 /* 1 if hi3d_gemm_bf16(d, stream) will fill d->gn_partial, 0 if that launch cannot (nothing is launched) */
 int hi3d_gemm_gn_partial_supported(const hi3d_gemm_desc* d, void* stream);
 /* ... or ask AFTER the launch: 1 when the last hi3d_gemm_bf16 call of the calling host thread filled gn_partial (one pass through
- * the dispatch instead of two; what hi3d_hip/ops.py does).                                                                     */
+ * the dispatch instead of two; what hi3d_hip/ops.py does).  The flag is PER HOST THREAD and is overwritten by every
+ * hi3d_gemm_bf16 / hi3d_gemm_gn_partial_supported / hi3d_debug_gemm_launch_info* call of that thread, launched or only
+ * described: ask immediately after the launch in question, with no other GEMM entry point in between.             */
 int hi3d_gemm_last_gn_fused(void);
+/* The dispatch reads its A/B switches (HI3D_GEMM_TILE_N, HI3D_GEMM_NO_NARROW, HI3D_GEMM_VARIANT, HI3D_GEMM_ABL, HI3D_GEMM_GN,
+ * HI3D_GEMM_SPLITK, HI3D_GN_FUSED_OFF) from the environment once per process (round 6: it used to call getenv up to seven times
+ * per launch).  A process that changes one of them while running -- the tests, tools/kbench.py sweeps -- calls this afterwards. */
+int hi3d_gemm_reload_env(void);
 
 /* ------------------------------------------------------------------------ */
 /* Attention                                                                 */

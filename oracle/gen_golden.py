@@ -138,6 +138,122 @@ def gen_sampler(name, cfg, T, hw, steps, max_scale, stage, wseed=1, iseed=0):
     print(f"{name}: final absmax {x.abs().max():.4f} std {x.std():.4f} ({time.time() - t0:.1f}s)")
 
 
+def _ref_sampler(unet, T, steps, max_scale):
+    Wrapper = ref_import.ref("sgm.modules.diffusionmodules.wrappers.OpenAIWrapper")
+    Denoiser = ref_import.ref("sgm.modules.diffusionmodules.denoiser.Denoiser")
+    Sampler = ref_import.ref("sgm.modules.diffusionmodules.sampling.EulerEDMSampler")
+    model = Wrapper(unet)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = Sampler(
+        num_steps=steps, verbose=False, device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                               "params": {"sigma_max": 700.0}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": max_scale, "min_scale": 1.0}})
+    extra = dict(image_only_indicator=torch.zeros(2, T), num_video_frames=T)
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+
+    return sampler, denoiser
+
+
+def _host_facts(threads):
+    import platform
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(threads=threads, cores=os.cpu_count(), cpu=model, torch=torch.__version__, python=platform.python_version(),
+                dtype="fp32", where="build container (no GPU)")
+
+
+def _ref_decode_frames(z, frames, ch=128, wseed=1):
+    """decode_first_stage (models/diffusion.py:117-135: z / scale_factor, AutoencoderKL.decode) + the pipeline's rearrange +
+    tensor2vid (pipeline_i2v_eval_v01.py:95-99, vtdm/util.py:13-21) of the REFERENCE on the frames `frames` of the clip z."""
+    import einops
+    AE = ref_import.ref("sgm.models.autoencoder.AutoencoderKL")
+    tensor2vid = ref_import.ref_vtdm_util("tensor2vid")
+    ae = AE(embed_dim=4, ddconfig=vae_ddconfig(ch), lossconfig={"target": "torch.nn.Identity"}).eval()
+    synth.fill_module_(ae, wseed, prefix=VAE_PREFIX)
+    imgs = []
+    with torch.no_grad():
+        for f in frames:                       # en_and_decode_n_samples_a_time: frames are independent in AutoencoderKL
+            imgs.append(ae.decode(z[f:f + 1] / 0.18215))
+    img = torch.cat(imgs, 0)
+    vid = tensor2vid(einops.rearrange(img.clone(), "(b t) c h w -> b c t h w", t=len(frames)))
+    return img, torch.from_numpy(__import__("numpy").stack(vid))
+
+
+def gen_sampler_at_size(name, cfg, T, hw, steps, n_run, max_scale, stage, wseed=1, iseed=0, decode_frames=None):
+    """The reference's EulerEDMSampler.step_call (sampling.py:93-147) + LinearPredictionGuider (guiders.py:78-99) + Denoiser
+    (denoiser.py:23-39) + OpenAIWrapper + VideoUNet at a BENCHMARKED size: the first `n_run` steps of the `steps`-step schedule.
+
+    What is stored per step is the guided denoised estimate D_i (the return value of EDMSampler.denoise, sampling.py:54-57, in
+    fp16: |D| is O(1)), NOT the state: at sigma_0 = 700 the state is ~2800 in magnitude and carries D with weight
+    1 - sigma_1/sigma_0, so a state stored in fp16 (resolution 2.0 at that magnitude) would not see the network at all, and a
+    state compared in relative max-abs terms would pass with a garbage network.  The test rebuilds the reference states from
+    x0 and the D_i with the Euler update (exact up to D's fp16 rounding, pinned against `last_state`, stored in fp32).
+    Compact: x0 / c / uc are re-drawn from `input_seed` by synth.synth_conditioning (pinned by `x0_probe`).  Records the wall time
+    of every step: this IS the metric's unit (one CFG-doubled denoise step) on the reference classes."""
+    t0 = time.time()
+    threads = torch.get_num_threads()
+    unet = build_unet(cfg, wseed)
+    t_build = time.time() - t0
+    sampler, denoiser = _ref_sampler(unet, T, steps, max_scale)
+    x0, c, uc = synth.synth_conditioning(T, hw, hw, stage=stage, seed=iseed, adm_in=cfg["adm_in_channels"])
+    Ds, step_s = [], []
+    ref_denoise = sampler.denoise
+
+    def recording_denoise(*a, **k):
+        d = ref_denoise(*a, **k)
+        Ds.append(d.to(torch.float16))
+        return d
+    sampler.denoise = recording_denoise
+    with torch.no_grad():
+        x, s_in, sigmas, num_sigmas, cond, ucond = sampler.prepare_sampling_loop(x0.clone(), c, uc, steps)
+        for i in sampler.get_sigma_gen(num_sigmas):
+            if i >= n_run:
+                break
+            t1 = time.time()
+            x = sampler.step_call(denoiser, x, i, s_in, sigmas, num_sigmas, cond, ucond)
+            step_s.append(time.time() - t1)
+            print(f"{name}: step {i} {step_s[-1]:.1f}s |x| {x.abs().max():.3f} |D| {Ds[-1].float().abs().max():.3f}", flush=True)
+    assert len(Ds) == n_run
+    fx = dict(kind="sampler_at_size", cfg=cfg, T=T, hw=hw, steps=steps, n_run=n_run, max_scale=max_scale, stage=stage,
+              weight_seed=wseed, key_prefix=UNET_PREFIX, input_seed=iseed,
+              x0_probe=dict(head=x0.flatten()[:16].clone(), sum=float(x0.double().sum()), abs_sum=float(x0.double().abs().sum())),
+              sigmas=sigmas, denoised_f16=torch.stack(Ds), last_state=x.clone(), last_step=n_run - 1,
+              ref_step_seconds=step_s, ref_build_seconds=t_build, ref_host=_host_facts(threads),
+              shapes_sha256=shapes_digest(unet.state_dict()))
+    if decode_frames:
+        del unet
+        t1 = time.time()
+        img, vid = _ref_decode_frames(x, decode_frames)
+        fx.update(decode_frames=list(decode_frames), decoded_f16=img.to(torch.float16), decoded_u8=vid,
+                  ref_decode_seconds=time.time() - t1)
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: {n_run} steps, mean {sum(step_s) / len(step_s):.1f}s/step, total {time.time() - t0:.0f}s", flush=True)
+
+
+def gen_decode_of(name, src, ch=128):
+    """Full-width end-to-end image golden: the REFERENCE's decode_first_stage + tensor2vid of the final latents an existing
+    reference-class sampler fixture holds (`src`.output) -- sample -> decode -> uint8 frames all from reference classes."""
+    t0 = time.time()
+    z = torch.load(os.path.join(GOLD, src + ".pt"), weights_only=False)["output"]
+    frames = list(range(z.shape[0]))
+    img, vid = _ref_decode_frames(z, frames, ch=ch)
+    fx = dict(kind="decode_of", src=src, ddconfig=vae_ddconfig(ch), weight_seed=1, key_prefix=VAE_PREFIX,
+              z_head=z.flatten()[:16].clone(), decoded=img, decoded_u8=vid)
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    print(f"{name}: img {tuple(img.shape)} absmax {img.abs().max():.3f} u8 {tuple(vid.shape)} ({time.time() - t0:.1f}s)")
+
+
 def gen_vae(name, ch, n, hw, wseed=1, iseed=0, compact=False):
     """compact: z is re-drawn from `input_seed` by the test (pinned by `z_head`), the image is stored in fp16."""
     t0 = time.time()
@@ -294,9 +410,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--full", action="store_true", help="also the full-size stage-1 UNet forward (~3 min, 8 cores)")
+    ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(8)
+    torch.set_num_threads(a.threads)
     jobs = {
         "schedule": lambda: gen_schedule("schedule"),
         "unet_tiny_s1": lambda: gen_unet("unet_tiny_s1", unet_cfg(1, 64), T=4, hw=16),
@@ -347,6 +464,19 @@ def main():
         # BASELINE config 4 at its REAL size: 2 x 32 views, latent 128 x 128 (M = 1,048,576 token rows), the reference's own classes,
         # one clip per call (~20 min per clip on 8 cores, ~45 GB peak)
         jobs["unet_s2_full_t32"] = lambda: gen_unet("unet_s2_full_t32", unet_cfg(2), T=32, hw=128, iseed=88, compact=True, halves=True)
+        # ---- round 6: the thing the bench times, at the size it times it (reference classes end to end) ----
+        # stage 2, 16 views, latent 128 x 128, CFG 1 -> 2: the first 3 Euler-EDM steps of the 25-step schedule through
+        # EulerEDMSampler.step_call (~15-25 min per step on 8 cores, ~45 GB peak); per-step wall time recorded
+        jobs["sampler_s2_full_3step"] = lambda: gen_sampler_at_size("sampler_s2_full_3step", unet_cfg(2), T=16, hw=128, steps=25, n_run=3,
+                                                                    max_scale=2.0, stage=2, iseed=31)
+        # BASELINE config 1 exactly: stage 1, 16 views @ 512 x 512 (latent 64 x 64), all 25 steps, CFG 1 -> 2.5, then the reference
+        # decode_first_stage + tensor2vid of frames 0 / 5 / 10 / 15 (~2 min per step on 8 cores)
+        jobs["sampler_s1_full_25step"] = lambda: gen_sampler_at_size("sampler_s1_full_25step", unet_cfg(1), T=16, hw=64, steps=25, n_run=25,
+                                                                     max_scale=2.5, stage=1, iseed=32,
+                                                                     decode_frames=(0, 5, 10, 15))
+        # reference decode + tensor2vid of the final latents of the two full-width 25-step fixtures (4 frames of 128 x 128)
+        jobs["sampler_s1_w320_25step_img"] = lambda: gen_decode_of("sampler_s1_w320_25step_img", "sampler_s1_w320_25step")
+        jobs["v02_w320_25step_img"] = lambda: gen_decode_of("v02_w320_25step_img", "v02_w320_25step")
     for k, fn in jobs.items():
         if a.only is None or a.only == k:
             fn()

@@ -69,3 +69,17 @@ def ref(path):
     install()
     mod, name = path.rsplit(".", 1)
     return getattr(importlib.import_module(mod), name)
+
+
+def ref_vtdm_util(name):
+    """ref_vtdm_util('tensor2vid') -> the reference's vtdm/util.py function.  That module imports cv2 / imageio / torchvision
+    at its top for the mp4 writer (vtdm/util.py:2-5); tensor2vid itself (vtdm/util.py:13-21) uses none of them, so they get the
+    same inert stand-ins as the four packages above."""
+    install()
+    for dep in ("cv2", "imageio", "torchvision"):
+        if dep not in sys.modules:
+            try:
+                importlib.import_module(dep)
+            except ImportError:
+                _stub(dep)
+    return getattr(importlib.import_module("vtdm.util"), name)

@@ -19,6 +19,7 @@ for p in (PKG, ROOT):
 ROW_TESTS = [
     ("a1-a6 sampler step / guider / denoiser / wrapper", [
         "test_unet_gpu.py::test_sampler_matches_reference_golden",
+        "test_timed_path_gpu.py::test_stage2_headline_sampler_steps_through_graph_and_two_streams_match_reference",
         "test_at_size_gpu.py::test_sampler_25_steps_full_width_matches_reference_golden",
         "test_unet_gpu.py::test_fused_graph_step_equals_generic_step",
         "test_kernels_gpu.py::test_cfg_prepare_and_sampler_step",
@@ -48,7 +49,9 @@ ROW_TESTS = [
     ("e multi-GPU: CFG split, frame<->space all-to-all, sharded decode", ["test_parallel_gpu.py::"]),
     ("f2 VAE encoder + v02 pre-loop, clips end to end", [
         "test_depth_gpu.py::test_v02_conditioner_end_to_end", "test_pipeline_gpu.py::test_stage2_clip_from_yaml",
-        "test_pipeline_gpu.py::test_stage1_clip_create_model_sample_decode"]),
+        "test_pipeline_gpu.py::test_stage1_clip_create_model_sample_decode",
+        "test_timed_path_gpu.py::test_stage1_clip_full_size_25_steps_and_decode_match_reference_end_to_end",
+        "test_timed_path_gpu.py::test_full_width_25_step_latents_decode_to_the_reference_images"]),
     ("f3 conditioner on the GPU", [
         "test_clip_gpu.py::test_openclip_prediction_embedder_end_to_end", "test_clip_gpu.py::test_aes_embedder_end_to_end",
         "test_clip_gpu.py::test_vit_runtime", "test_depth_gpu.py::test_depth_embedder", "test_depth_gpu.py::test_dpt_hybrid_matches_reference_midas"]),
@@ -83,6 +86,38 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _gemm_env_follows_monkeypatch(request, monkeypatch):
+    """The GEMM dispatch caches its HI3D_GEMM_* switches per process (hi3d_gemm_reload_env).  Tests flip them with
+    monkeypatch.setenv: this wrapper makes setenv / delenv of such a name re-read the cache at once, and re-reads it again after
+    the test, when monkeypatch has restored the environment (this fixture depends on monkeypatch, so it is torn down FIRST --
+    hence the explicit undo here before the final reload)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from hi3d_hip import ops
+    names = ("HI3D_GEMM_", "HI3D_GN_FUSED_OFF")
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        set_(name, value, *a, **k)
+        if name.startswith(names):
+            ops.gemm_reload_env()
+
+    def delenv(name, *a, **k):
+        del_(name, *a, **k)
+        if name.startswith(names):
+            ops.gemm_reload_env()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    ops.gemm_reload_env()
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch
@@ -102,17 +137,31 @@ def shrink_conditioner(y):
     return y
 
 
-_UNET_WEIGHTS = {}          # (state_dict key, shape, seed) -> fp32 tensor on the device: drawn once per session
+_SYNTH_WEIGHTS = {}         # (state_dict key, shape, seed, device) -> fp32 tensor on the device: drawn once per session
+
+
+def synth_fill_cached(module, key_prefix, seed, dev):
+    """Load the hi3d_hip.synth weights (the CPU stream: the values the reference modules got when a golden was made) of the
+    keys `key_prefix + k` into `module`, which already lives on `dev`.  The drawn tensors are kept on the device for the session,
+    per TENSOR -- the stage-1 / stage-2 networks (same keys but the input conv) share them -- because drawing 1.5 B parameters on
+    the host was half of the GPU suite's wall time."""
+    from hi3d_hip import synth
+    sd = {}
+    for k, v in module.state_dict().items():
+        if v.dtype.is_floating_point:
+            ck = (key_prefix + k, tuple(v.shape), seed, str(dev))
+            if ck not in _SYNTH_WEIGHTS:
+                _SYNTH_WEIGHTS[ck] = synth.synth_tensor(ck[0], v.shape, seed).to(dev)
+            sd[k] = _SYNTH_WEIGHTS[ck]
+    module.load_state_dict(sd, strict=False)
+    return module
 
 
 def synth_unet(fx, dev):
-    """A fresh VideoUNet(**fx["cfg"]) on `dev` carrying the fixture's seeded weights (hi3d_hip.synth: the CPU stream, the
-    same values the reference modules got when the golden was made).  Every test gets its OWN module (its own runtime,
-    built under the test's environment); what is shared for the session is the drawn state dict, kept on the device --
-    drawing 1.5 B parameters on the host and torch's default init of a module that is overwritten anyway were half of the
-    GPU suite's wall time."""
+    """A fresh VideoUNet(**fx["cfg"]) on `dev` carrying the fixture's seeded weights.  Every test gets its OWN module (its own
+    runtime, built under the test's environment); what is shared for the session is the drawn state dict (synth_fill_cached);
+    torch's default init of a module that is overwritten anyway is skipped."""
     import torch
-    from hi3d_hip import synth
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     from sgm.util import ParamTree
     ParamTree.skip_init = True
@@ -121,12 +170,4 @@ def synth_unet(fx, dev):
             m = VideoUNet(**fx["cfg"])
     finally:
         ParamTree.skip_init = False
-    sd = {}
-    for k, v in m.state_dict().items():           # per TENSOR, so the stage-1 / stage-2 networks (same keys but the input conv) share
-        if v.dtype.is_floating_point:
-            ck = (fx["key_prefix"] + k, tuple(v.shape), fx["weight_seed"], str(dev))
-            if ck not in _UNET_WEIGHTS:
-                _UNET_WEIGHTS[ck] = synth.synth_tensor(ck[0], v.shape, fx["weight_seed"]).to(dev)
-            sd[k] = _UNET_WEIGHTS[ck]
-    m.load_state_dict(sd, strict=False)
-    return m
+    return synth_fill_cached(m, fx["key_prefix"], fx["weight_seed"], dev)

@@ -5,7 +5,9 @@ the reference classes -- not only the small shapes of test_kernels_gpu.py.
 
 Same tolerances as the small-shape tests (bf16 storage, fp32 accumulation):
   kernels  : max-abs error <= 1.2e-2 x max-abs reference (2e-2 for attention, P is bf16)
-  UNet     : <= 4e-2, cosine >= 0.9995        25-step latents: cosine >= 0.999, <= 6e-2
+  UNet     : <= 2.5e-2, cosine >= 0.9998 at the full sizes (round 6: tightened from 4e-2 / 0.9995 -- measured 1.5 - 2.0e-2 /
+             0.99989 on every full-size golden, so a kernel regression of 2x in error used to pass)
+  25-step latents: cosine >= 0.999, <= 6e-2
   VAE image: <= 4e-2, PSNR >= 35 dB
 """
 import math
@@ -191,8 +193,8 @@ def _build_unet(fx, dev):
 @pytest.mark.parametrize("attn", ["bf16", "fp8qk", "fp8"])
 def test_unet_full_size_stage2_matches_reference_golden(dev, attn, monkeypatch):
     """THE benchmarked forward: B = 2x16 frames, 17 input channels, latent 128x128 (S = 16384 tokens,
-    M = 524288-row GEMMs), against one forward of the reference VideoUNet (fp32 CPU).  bf16: the framework's tolerance
-    (4e-2, cos >= 0.9995).  BASELINE config 5 at size, each reduced-precision attention under its own stated tolerance:
+    M = 524288-row GEMMs), against one forward of the reference VideoUNet (fp32 CPU).  bf16: the full-size tolerance
+    (2.5e-2, cos >= 0.9998).  BASELINE config 5 at size, each reduced-precision attention under its own stated tolerance:
     fp8qk (score product on e4m3) 8e-2 / cos >= 0.998; fp8 (both products) 1.2e-1 / cos >= 0.995."""
     from hi3d_hip import synth
     monkeypatch.setenv("HI3D_ATTN_FP8QK", "1" if attn == "fp8qk" else "0")
@@ -212,7 +214,7 @@ def test_unet_full_size_stage2_matches_reference_golden(dev, attn, monkeypatch):
     rel, c = relerr(out, ref), cos(out, ref)
     print(f"unet_s2_full [{attn}]: rel {rel:.4f} cos {c:.6f}")
     assert tuple(out.shape) == tuple(ref.shape) == (32, 4, 128, 128)
-    tol, cmin = {"bf16": (4e-2, 0.9995), "fp8qk": (8e-2, 0.998), "fp8": (1.2e-1, 0.995)}[attn]
+    tol, cmin = {"bf16": (2.5e-2, 0.9998), "fp8qk": (8e-2, 0.998), "fp8": (1.2e-1, 0.995)}[attn]
     assert rel < tol and c > cmin
 
 
@@ -222,7 +224,7 @@ def test_unet_config4_full_size_matches_reference_golden(dev):
     128 x 128, 1,048,576 token rows, 16384-token spatial attention at B = 64, temporal attention / Conv3d / 3-D GroupNorm over 32
     frames -- in ONE forward on the GPU (the product's batch of 64), against the reference's own VideoUNet run on the CPU one
     clip per call (the two clips never mix inside the network; 90 GB in one call, 45 GB this way; oracle/gen_golden.py
-    `unet_s2_full_t32`, ~40 min).  Same tolerance as the 16-view forward: 4e-2 of the output range, cosine >= 0.9995."""
+    `unet_s2_full_t32`, ~40 min).  Same tolerance as the 16-view forward: 2.5e-2 of the output range, cosine >= 0.9998."""
     from hi3d_hip import synth
     if not os.path.exists(os.path.join(GOLD, "unet_s2_full_t32.pt")):
         pytest.skip("unet_s2_full_t32.pt not generated")
@@ -241,7 +243,7 @@ def test_unet_config4_full_size_matches_reference_golden(dev):
     rel, c = relerr(out, ref), cos(out, ref)
     relh = [relerr(out[b * T:(b + 1) * T], ref[b * T:(b + 1) * T]) for b in (0, 1)]
     print(f"unet_s2_full_t32 (config 4, 64 frames @ 128^2): rel {rel:.4f} cos {c:.6f}; per clip {relh[0]:.4f} / {relh[1]:.4f}")
-    assert rel < 4e-2 and c > 0.9995
+    assert rel < 2.5e-2 and c > 0.9998
 
 
 @pytest.mark.parametrize("name", ["unet_s2_lat16_t32", "unet_s2_lat64_t32"])
@@ -265,7 +267,7 @@ def test_unet_full_width_32_views_matches_reference_golden(dev, name):
     ref = fx["output"].float()
     rel, c = relerr(out, ref), cos(out, ref)
     print(f"unet full width, 32 views, latent {hw} vs reference: rel {rel:.4f} cos {c:.6f}")
-    assert T == 32 and tuple(out.shape) == (2 * T, 4, hw, hw) == tuple(ref.shape) and rel < 4e-2 and c > 0.9995
+    assert T == 32 and tuple(out.shape) == (2 * T, 4, hw, hw) == tuple(ref.shape) and rel < 2.5e-2 and c > 0.9998
 
 
 def test_sampler_25_steps_full_width_matches_reference_golden(dev):

@@ -220,12 +220,14 @@ def bench_sweep():
                     os.environ.pop(ENV, None)
                 else:
                     os.environ[ENV] = v
+                ops.gemm_reload_env()          # (the dispatch caches its switches per process)
                 try:
                     ms = timeit(fn, iters=4, warm=1)
                 except Exception as e:  # noqa: BLE001
                     ms = float("nan")
                 best[v] = min(best.get(v, 1e9), ms)
         os.environ.pop(ENV, None)
+        ops.gemm_reload_env()
         cells = "  ".join(f"{v}:{best[v]:7.3f}ms {fl / best[v] / 1e9:6.0f}TF" for v in vs)
         print(f"  {label:52s} {cells}", flush=True)
 
