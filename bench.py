@@ -591,7 +591,7 @@ def unet_bench(a, stage, T, attn, rank, world, dev, use_dist, steps, warmup, pro
         log(f"[bench] kernels total {total_ms / steps:.2f} ms/step; wall {ms_per_step:.2f} ms/step "
             f"({'graph replay' if graphed else 'eager'}), {eager_ms:.2f} ms/step eager with events")
         if a.shapes:
-            for fam, d in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            for fam, d in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:90]:
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 log(f"[bench]   {fam:60s} {d['ms'] / steps:8.3f} ms/step {d['launches'] // steps:4d}x "

@@ -63,7 +63,6 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int nk = p.ksplit > 1 ? p.nk_split : p.K / BK;
   // logical id -> tile.  n fastest (measured 15x less L2 -> fabric fetch than m fastest); and when the weight matrix does not
   // fit an XCD's 4 MB L2 (GEGLU: 6.5 - 26 MB; round-2 PMC: W re-streamed from the Infinity Cache for every pair of m-tiles,
   // 15x its size per launch), in COLUMN GROUPS of gn n-tiles: the blocks resident on an XCD cover (32 / gn) m-tiles x gn
@@ -78,6 +77,18 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     tm = rem / gw; tn = g * p.gn + rem - tm * gw;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  // Conv3d (3,1,1), clip boundaries: when the block's rows lie in one frame (HW % BM == 0) and that frame is the first / last
+  // of its clip, tap 0 / tap 2 reads nothing but the clip's zero padding -- its K steps are left out (2 of 3 T taps of such a
+  // block: 4 % of the launch at T = 16).  Block-uniform: scalar registers only.
+  int tap_lo = 0, tap_hi = AMODE_ == HI3D_A_CONV3X3 || AMODE_ == A_CONV3X3_UP2X ? p.ntap : 3;
+  int nk_ = p.ksplit > 1 ? p.nk_split : p.K / BK;
+  if (AMODE_ == HI3D_A_CONVT3 && p.tskip && p.ksplit <= 1 && p.HW % BM == 0 && p.T > 1) {
+    const int t = (m0 / p.HW) % p.T;
+    if (t == 0) tap_lo = 1;
+    if (t == p.T - 1) tap_hi = 2;
+    nk_ = (tap_hi - tap_lo) * (p.Cin / BK);
+  }
+  const int nk = nk_;
 
 
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       0, 0x7fffffff, 0x00020000);
 
   // conv modes: current tap and channel offset of the K chunk (split-K starts at a slab boundary: nk is a multiple of the taps)
-  int tap = 0, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? p.ntap : 3)) * BK;
+  int tap = tap_lo, c0 = AMODE == HI3D_A_DENSE ? 0 : ks * (nk / (AMODE == HI3D_A_CONV3X3 ? p.ntap : 3)) * BK;
 
   // LDS-DMA pieces [LO, HI) of K chunk `kt` into ring slot `st`: pieces 0..3 are this wave's A rows, 4.. its W rows
   // (the ping-pong loop spreads the pieces of a stage over its phases; the plain loops issue them all at once)
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // HBM / the fabric once and the other taps hit L2.  (Round 1 walked taps outermost and re-fetched the
   // input per tap: FETCH_SIZE 6.5x the algorithmic bytes.)
   auto advance_k = [&]() {
-    if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= (AMODE == HI3D_A_CONV3X3 ? p.ntap : 3)) { tap = 0; c0 += BK; } }
+    if (AMODE != HI3D_A_DENSE) { ++tap; if (tap >= tap_hi) { tap = tap_lo; c0 += BK; } }
   };
   auto issue = [&](int kt, int st) {
     issue_pieces(kt, st, std::integral_constant<int, 0>{}, std::integral_constant<int, 4 + W_PIECES>{});
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     // (sum, sum of squares) pairs over its 4 x 4*NT values, a 4-step butterfly over the 16 lanes that hold the other rows,
     // one 8*NG-byte store per (64-row block, column quarter).  Every (block, group) pair is written by exactly one lane of the
     // grid: plain stores, fixed summation order, bitwise reproducible.  The accumulators already carry bias + row vector.
-    if (EPI == HI3D_EPI_AFFINE && p.gn_part) {
+    auto emit_gn_stats = [&]() {
       constexpr int LC = 4 * NT;
       auto gn_block = [&](auto ng_) {
         constexpr int NG = decltype(ng_)::value, CPG = LC / NG;
@@ -578,7 +589,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       if (cpg * 4 == LC) gn_block(std::integral_constant<int, 4>{});
       else if (cpg * 2 == LC) gn_block(std::integral_constant<int, 2>{});
       else gn_block(std::integral_constant<int, 1>{});
-    }
+    };
+    if (EPI == HI3D_EPI_AFFINE && p.gn_part && !p.gn_post) emit_gn_stats();
     const __amdgpu_buffer_rsrc_t rsOw =
         __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
     // chunk i of a pass = lane + 64 i: slab row / column, the same in all four passes -- its LDS, bias, output and
@@ -619,6 +631,60 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     const bool wfast = !p.out_fp32 && p.vec8 && rows_left >= 64 && wcol0 + WOUT <= N_out && (ugrp || !(p.rowvec || p.a1 || p.a2));
     u32x4 q1[2][WCH];        // (R2 -- AlphaBlender tails -- is loaded at the point of use: a third register set spills)
     __syncthreads();                               // every wave is done with the operand ring
+    // ---- GroupNorm statistics of a tile that adds residual / blend terms AFTER its accumulators (GemmParams.gn_post; round 6): the
+    // terms are added HERE, in the accumulator layout, so that the statistics come from the same registers and the same DPP
+    // butterfly as above and the store loop below runs its residual-free path.  The R tile of 32 rows x WOUT columns (bf16, row-
+    // contiguous: the chunk offsets of the store pass) goes to this wave's slab by LDS-DMA -- no registers -- and is read back
+    // as the lane's 4*NT consecutive columns of its row, 8 at a time.  Same operations in the same order as the store loop
+    // ((acc + R1) * a1 + a2 * R2, fp32).  (A first form took the sums in the store loop with ds_add_f32 into a pair table: the LDS
+    // atomics cost 20 ms per step, profiles/r06b_ab_gn_post_atomics.log.)
+    const bool gn_post = EPI == HI3D_EPI_AFFINE && p.gn_part && p.gn_post;
+    if constexpr (EPI == HI3D_EPI_AFFINE) if (gn_post) {
+      constexpr int RROW = WOUT * 2;                                       // bytes of a slab row of the bf16 R tile
+      static_assert(32 * RROW <= WSLAB && 16 * RROW == WCH * 1024, "R tile: 16 rows = WCH LDS-DMA pieces, 32 rows fit the slab");
+      auto add_tile = [&](const __amdgpu_buffer_rsrc_t& rs, const unsigned (&off)[WCH], int ldr, auto second) {
+        constexpr bool R2T = decltype(second)::value;                    // false: acc += R1;  true: acc += ts2 * R2
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int i = 0; i < WCH; ++i)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(slab + sub * 16 * RROW + i * 1024), 16, off[i],
+                                                       (half * 2 + sub) * 16 * ldr * 2, 0, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const int mt = half * 2 + sub;
+            const char* rrow = slab + (sub * 16 + fr) * RROW + fg * (8 * NT);
+#pragma unroll
+            for (int n2 = 0; n2 < NT / 2; ++n2) {
+              const u32x4 r = *(const u32x4*)(rrow + n2 * 16);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(r[j] << 16), hi = __uint_as_float(r[j] & 0xffff0000u);
+                f32x4& a = acc[mt][2 * n2 + (j >> 1)];
+                if (R2T) { a[(j & 1) * 2] += ts2 * lo; a[(j & 1) * 2 + 1] += ts2 * hi; }
+                else { a[(j & 1) * 2] += lo; a[(j & 1) * 2 + 1] += hi; }
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the reads are done before the next pieces land
+          __builtin_amdgcn_wave_barrier();
+        }
+      };
+      static_assert(NT % 2 == 0, "R tile read-back: 8 columns at a time");
+      if (p.R1) add_tile(rsR1, w_r1, p.ldr1, std::false_type{});
+      if (p.a1) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { acc[mt][nt][0] *= ts1; acc[mt][nt][1] *= ts1; acc[mt][nt][2] *= ts1; acc[mt][nt][3] *= ts1; }
+      }
+      if (p.R2) add_tile(rsR2, w_r2, p.ldr2, std::true_type{});
+      emit_gn_stats();
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       char* trow = slab + fr * WROW;
@@ -638,7 +704,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           *(f32x4*)(trow + cw * 4) = v;
         }
       }
-      if (EPI == HI3D_EPI_AFFINE && p.R1) {        // residual slabs one pass ahead (pass 0 together with pass 1)
+      if (EPI == HI3D_EPI_AFFINE && p.R1 && !gn_post) {        // residual slabs one pass ahead (pass 0 together with pass 1)
         __builtin_amdgcn_sched_barrier(0);
         if (mt == 0) wfetch(0, q1[0]);
         if (mt + 1 < 4) wfetch(mt + 1, q1[(mt + 1) & 1]);
@@ -659,16 +725,16 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
               for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
             }
-            if (p.R1) {
+            if (p.R1 && !gn_post) {
               const u32x4 r = q1[mt & 1][i];
 #pragma unroll
               for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(r[j] << 16); v[2 * j + 1] += __uint_as_float(r[j] & 0xffff0000u); }
             }
-            if (p.a1) {
+            if (p.a1 && !gn_post) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] *= ts1;
             }
-            if (p.R2) {
+            if (p.R2 && !gn_post) {
               const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsR2, w_r2[i], mt * 16 * p.ldr2 * 2, 0);
 #pragma unroll
               for (int j = 0; j < 4; ++j) { v[2 * j] += ts2 * __uint_as_float(r[j] << 16); v[2 * j + 1] += ts2 * __uint_as_float(r[j] & 0xffff0000u); }
@@ -973,6 +1039,8 @@ struct GemmEnv {
   int abl = 0;                      // HI3D_GEMM_ABL (ablation bits of the epilogue study)
   bool has_gn = false; int gn = 0;  // HI3D_GEMM_GN: column-group width of the tile raster
   bool gn_fused_off = false;        // HI3D_GN_FUSED_OFF set
+  bool gn_post_off = false;         // HI3D_GN_POST=0: no statistics from residual / blend epilogues (round-5 behaviour; A/B switch)
+  bool convt_skip = true;           // HI3D_CONVT_SKIP=0: Conv3d (3,1,1) walks all three taps in every block (A/B switch)
   int splitk = -1;                  // HI3D_GEMM_SPLITK: 0 = never, S > 1 = force S, -1 = heuristic
   void load() {
     *this = GemmEnv{};
@@ -982,6 +1050,8 @@ struct GemmEnv {
     if (const char* e = getenv("HI3D_GEMM_ABL")) abl = atoi(e);
     if (const char* e = getenv("HI3D_GEMM_GN")) { has_gn = true; gn = atoi(e); }
     gn_fused_off = getenv("HI3D_GN_FUSED_OFF") != nullptr;
+    if (const char* e = getenv("HI3D_GN_POST")) gn_post_off = atoi(e) == 0;
+    if (const char* e = getenv("HI3D_CONVT_SKIP")) convt_skip = atoi(e) != 0;
     if (const char* e = getenv("HI3D_GEMM_SPLITK")) splitk = atoi(e);
   }
 };
@@ -1027,7 +1097,8 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (d->rows_per_group % 256 || d->M % d->rows_per_group)
       HI3D_FAIL(HI3D_ESHAPE, "gemm: per-group weights need rows_per_group % 256 == 0 (the tallest tile) and M % rows_per_group == 0");
   }
-  p.gn_part = nullptr; g_gn_fused = 0;
+  p.gn_part = nullptr; p.gn_post = 0; g_gn_fused = 0;
+  p.tskip = env.convt_skip ? 1 : 0;
   const bool two = d->A2 != nullptr;
   if (two) {
     if (d->amode != HI3D_A_DENSE || d->epi != HI3D_EPI_AFFINE) HI3D_FAIL(HI3D_ESHAPE, "gemm: A2 (two-source A) needs dense A and the affine epilogue");
@@ -1166,11 +1237,20 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // GroupNorm statistics of the output from the producer's accumulators (GemmParams.gn_part): the wide ping-pong tile, full
   // tiles only, nothing added after the accumulators (no residual / blend; a row vector only when it is per tile), and a
   // channel count whose groups are whole inside a lane's 4*NT columns
-  if (d->gn_partial && (variant == 7 || variant == 8) && d->epi == HI3D_EPI_AFFINE && !d->R1 && !d->R2 && !d->a1 && !d->a2 &&
+  p.gn_post = 0;
+  if (d->gn_partial && (variant == 7 || variant == 8) && d->epi == HI3D_EPI_AFFINE &&
       !d->out_fp32 && d->M % 256 == 0 && d->N % tile == 0 && d->N % 32 == 0 && (!d->rowvec || d->rows_per_group % 256 == 0) &&
       ((uintptr_t)d->gn_partial & 7) == 0 && !env.gn_fused_off) {
     const int lc = tile == 320 ? 40 : 32, cpg = d->N / 32;
-    if (cpg == lc || cpg * 2 == lc || cpg * 4 == lc) { p.gn_part = d->gn_partial; g_gn_fused = 1; }
+    const bool whole = cpg == lc || cpg * 2 == lc || cpg * 4 == lc;        // groups are whole inside a lane's 4*NT columns
+    if (!d->R1 && !d->R2 && !d->a1 && !d->a2) {
+      if (whole) { p.gn_part = d->gn_partial; g_gn_fused = 1; }
+    } else if (whole && !env.gn_post_off && p.vec8 && ((!d->a1 && !d->a2) || d->rows_per_group % 256 == 0)) {
+      // residual / blend terms after the accumulators (round 6): they are added in the accumulator layout before the store loop
+      // (GemmParams.gn_post), the statistics taken from the final values.  Full tiles, bf16 out, 16-byte rows, one row group per
+      // tile: every wave tile takes the kernel's interior store path
+      p.gn_part = d->gn_partial; p.gn_post = 1; g_gn_fused = 1;
+    }
   }
   if (tile == 256) return dispatch<4, 8, 2, true>(p, amode, d->epi, s);
   if (tile == 320) return variant == 7 ? dispatch<4, 10, 2, true>(p, amode, d->epi, s) : dispatch<4, 10, 2>(p, amode, d->epi, s);

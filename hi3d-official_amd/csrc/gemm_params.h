@@ -32,6 +32,13 @@ struct GemmParams {
   // reads, so the consuming GroupNorm skips its statistics pass over the tensor (openaimodel.py:292-294 out_layers.0 after
   // in_layers.2; video_model.py time_stack likewise).  nullptr = off.
   float* gn_part;
+  // 1: the launch adds residual / blend terms after its accumulators (R1 / R2 / a1 / a2): the statistics are taken in the store
+  // loop instead, from the FINAL values as they are rounded to bf16 (round 6) -- the GroupNorm that reads a ResBlock's or a
+  // transformer's output (openaimodel.py:328-354 in_layers.0; video_model.py:62-81 time_stack.in_layers.0; attention.py:702 norm)
+  int gn_post;
+  // Conv3d (3,1,1): a block whose rows lie in ONE frame at either end of its clip skips the K steps of the tap that reads the
+  // clip's zero padding (round 6; 0 = walk all three taps, HI3D_CONVT_SKIP=0)
+  int tskip;
 };
 
 constexpr int BK = 64;

@@ -383,8 +383,9 @@ def _groupnorm_silu(x, gamma, beta, inst, P, C, eps, silu, out, x2=None, partial
         C1 = x.numel() // (inst * P)
         _l.check(_lib.hi3d_groupnorm_silu_cat2(_p(x), _p(x2), _p(out), _p(gamma), _p(beta), _p(ws), inst, P, C1, C - C1,
                                                float(eps), 1 if silu else 0, _stream()), "hi3d_groupnorm_silu_cat2")
-    if prof:   # algorithmic bytes: read x once + write y once; the kernel reads x twice
-        prof.end("groupnorm_silu", 0.0, 2.0 * 2 * inst * P * C, t0)
+    if prof:   # algorithmic bytes: read x once + write y once; the three-pass form reads x twice
+        prof.end("groupnorm_silu", 0.0, 2.0 * 2 * inst * P * C, t0,
+                 detail=f"inst={inst} P={P} C={C} {'from-partials' if partials is not None else 'cat2' if x2 is not None else '3-pass'}")
     return out
 
 
@@ -459,7 +460,7 @@ def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum
     _l.check(_lib.hi3d_layernorm(_p(x), _p(out), _p(sum_out), _p(gamma), _p(beta), _p(addvec),
                                  rows_per_group, R, C, float(eps), _stream()), "hi3d_layernorm")
     if prof:
-        prof.end("layernorm", 0.0, 2.0 * R * C * (3 if sum_out is not None else 2), t0)
+        prof.end("layernorm", 0.0, 2.0 * R * C * (3 if sum_out is not None else 2), t0, detail=f"R={R} C={C}")
     return out
 
 

@@ -202,14 +202,15 @@ class FrameSpaceGroup:
         # skip tensors do) would see it overwritten two exchanges later (found by the 8-rank two-communicator test: B * Tl = 1)
         return y.clone() if y.data_ptr() == x.data_ptr() else y
 
-    def frames_to_space(self, x, B, S):
+    def frames_to_space(self, x, B, S, borrow=False):
         """[B*Tl*S, C] (b tl s) -> [B*T*Sl, C] (b t sl).
 
-        LIFETIME (B == 1, the CFG-split mapping): the result is a VIEW of one of the two persistent receive buffers of this
-        shape -- no unpack copy is needed, so none is made -- and stays valid until the SECOND-next exchange of the same shape.
-        Both callers (runtime_unet._res / _transformer) consume it inside their block, before the block's own
-        space_to_frames: do not keep it (as a skip tensor, say) beyond that; space_to_frames always returns a fresh tensor.
-        HI3D_A2A_POISON=1 turns a violation into NaNs (tests/test_parallel_gpu.py runs the clip-parallel step under it)."""
+        LIFETIME (B == 1, the CFG-split mapping): no unpack copy is needed there -- the received buffer already IS the result.
+        `borrow=True` returns that VIEW of one of the two persistent receive buffers of this shape, valid until the SECOND-next
+        exchange of the same shape: for callers that consume it inside their block, before the block's own space_to_frames
+        (runtime_unet._res / _transformer pass it).  Without it (the default) the result is a fresh tensor a caller
+        may keep -- one device copy.  space_to_frames always returns a fresh tensor.  HI3D_A2A_POISON=1 turns a borrowed view
+        held too long into NaNs (tests/test_parallel_gpu.py runs the clip-parallel step under it)."""
         w, Tl, Sl, C = self.world, self.Tl, self._check(S), x.shape[-1]
         if w == 1:
             return x
@@ -217,6 +218,8 @@ class FrameSpaceGroup:
         recv = self._a2a(send)                                                     # [src][b][tl][sl][c]: src owns frames src*Tl..
         if B > 1:                                                                  # (b, (src tl) = t, sl); nothing to move when B == 1
             recv = self._perm(recv, (w, B, Tl * Sl, 1), (1, 0, 2, 3))
+        elif not borrow:
+            recv = recv.clone()
         return recv.reshape(B * self.T * Sl, C)
 
     def space_to_frames(self, x, B, S):

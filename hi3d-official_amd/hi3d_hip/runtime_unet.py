@@ -278,19 +278,23 @@ class UNetRuntime:
         return self._pos_cache[key]
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all, sp=None, emb_full=None, B=None, x2=None):
+    def _res(self, p, x, Cin, Cout, F_, H, Wd, T, emb_all, a1_all, sp=None, emb_full=None, B=None, x2=None, gp_in=None):
         """VideoResBlock (video_model.py:62-81).  F_: frames held by this GPU.  With `sp` (a
         hi3d_hip.parallel.FrameSpaceGroup) the spatial ResBlock runs on this GPU's frames, the temporal one
         on its pixels of ALL frames (all-to-all before and after, GroupNorm sums all-reduced).
         x2: the block input is the channel concatenation [x | x2] (`th.cat([h, hs.pop()], dim=1)`, video_model.py:490-499;
         Cin = both widths together), read in place by the two consumers -- the in_layers GroupNorm and the 1x1
-        skip_connection as two K segments -- instead of being materialised (round 4; HI3D_CAT_FUSED=0 restores the copy)."""
+        skip_connection as two K segments -- instead of being materialised (round 4; HI3D_CAT_FUSED=0 restores the copy).
+        gp_in: the GroupNorm partial sums of x that its PRODUCER emitted (round 6: also from epilogues that add a residual / blend
+        term -- the previous block's proj_out + x, its time_stack blend, a down-sampling conv), or None.
+        Returns (out, gp_out): gp_out = the partial sums of `out` for the GroupNorm that reads it next, or None."""
         W, HW = self.W, H * Wd
         B = F_ // T if B is None else B
         M = F_ * HW
         geo = dict(Hin=H, Win=Wd, Cin=Cin, Hout=H, Wout=Wd, stride=1, up2x=0)
         eo, _ = self.emb_slices[p]
-        h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5, x2=x2)
+        h = ops.groupnorm_silu(x, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.b"], F_, HW, Cin, 1e-5, x2=x2,
+                               partials=gp_in if x2 is None else None)
         # (the conv also emits the partial sums of the GroupNorm that reads its output: no statistics pass over h)
         h, gp = ops.gemm(h, W[p + ".in_layers.2.w"], M=M, N=Cout, K=9 * Cin, bias=W[p + ".in_layers.2.b"],
                          rowvec=emb_all[:, eo:], ldrv=self.emb_total, rows_per_group=HW, conv3x3=geo, gn=(F_, HW))
@@ -301,8 +305,9 @@ class UNetRuntime:
         else:
             skip = x if (p + ".skip.w") not in W else self._linear(x, p + ".skip", M)
         geo2 = dict(geo, Cin=Cout)
-        xs = ops.gemm(h, W[p + ".out_layers.3.w"], M=M, N=Cout, K=9 * Cout, bias=W[p + ".out_layers.3.b"],
-                      R1=skip, conv3x3=geo2)
+        # (+ the partial sums of xs = conv + skip for the 3-D GroupNorm of the time_stack, from the conv's store loop)
+        xs, gpx = ops.gemm(h, W[p + ".out_layers.3.w"], M=M, N=Cout, K=9 * Cout, bias=W[p + ".out_layers.3.b"],
+                           R1=skip, conv3x3=geo2, gn=(B, T * HW) if sp is None else (0, 0))
         # temporal ResBlock on the same memory: GroupNorm over (t,h,w) per clip, Conv3d (3,1,1)
         q = p + ".time_stack"
         eo, _ = self.emb_slices[q]
@@ -311,12 +316,12 @@ class UNetRuntime:
             gn3 = lambda t, k, gp=None: ops.groupnorm_silu(t, W[k + ".g"], W[k + ".b"], B, T * HW, Cout, 1e-5, partials=gp)
         else:                                   # rows (b t s_local): every frame, this GPU's pixels
             HWt, emb_t = HW // sp.world, emb_full
-            xs = sp.frames_to_space(xs, B, HW)
+            xs = sp.frames_to_space(xs, B, HW, borrow=True)      # (consumed inside this block: no unpack copy at B == 1)
             gn3 = lambda t, k, gp=None: ops.groupnorm_silu_sharded(t, W[k + ".g"], W[k + ".b"], B, T * HWt, Cout, 1e-5,
                                                                    sp.allreduce_sum_, sp.world)
         Mt = B * T * HWt
         tg = dict(T=T, HW=HWt, Cin=Cout)
-        h = gn3(xs, q + ".in_layers.0")
+        h = gn3(xs, q + ".in_layers.0", gpx)
         # (single GPU: the Conv3d emits the partial sums of the 3-D GroupNorm that follows; a space-sharded clip needs this
         # GPU's sums for the all-reduce and keeps the separate pass -- gn = (0, 0) never qualifies)
         h, gp = ops.gemm(h, W[q + ".in_layers.2.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"],
@@ -324,11 +329,14 @@ class UNetRuntime:
                          gn=(B, T * HWt) if sp is None else (0, 0))
         h = gn3(h, q + ".out_layers.0", gp)
         # alpha*x_s + (1-alpha)*(x_s + h_t)  ==  x_s + (1-alpha)*h_t     (video_model.py:77-79)
-        out = ops.gemm(h, W[q + ".out_layers.3.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
-                       a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HWt, convt3=tg)
-        return out if sp is None else sp.space_to_frames(out, B, HW)
+        # (+ the partial sums of the block's OUTPUT for whichever GroupNorm reads it next: the transformer's norm, the next
+        # ResBlock's in_layers.0)
+        out, gpo = ops.gemm(h, W[q + ".out_layers.3.w"], M=Mt, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
+                            a1=a1_all[self.mix_index[p]], R2=xs, rows_per_group=HWt, convt3=tg,
+                            gn=(F_, HW) if sp is None else (0, 0))
+        return (out, gpo) if sp is None else (sp.space_to_frames(out, B, HW), None)
 
-    def _transformer(self, p, x, C, F_, S, T, cond, a1_all, a_all, sp=None, B=None):
+    def _transformer(self, p, x, C, F_, S, T, cond, a1_all, a_all, sp=None, B=None, gp_in=None):
         """SpatialVideoTransformer (video_attention.py:230-301).  With `sp`: spatial block on this GPU's
         frames, temporal block (+ AlphaBlender) on its pixels of all frames."""
         W, M, Hh = self.W, F_ * S, C // 64
@@ -342,7 +350,7 @@ class UNetRuntime:
                                                 W[p + ".proj_in.w"], W[p + ".proj_in.b"], C)
             h = ops.gemm(x, Wf, M=M, N=C, K=C, rowvec=bf_, rows_per_group=S, w_group_stride=C * C)
         else:
-            xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False)
+            xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False, partials=gp_in)
             h = self._linear(xn, p + ".proj_in", M)
         # --- spatial block (attention.py:551-572)
         n = ops.layernorm(h, W[sp_ + ".norm1.g"], W[sp_ + ".norm1.b"], M, C)
@@ -358,7 +366,7 @@ class UNetRuntime:
         St = S
         if sp is not None:
             St = S // sp.world
-            h = sp.frames_to_space(h, B, S)
+            h = sp.frames_to_space(h, B, S, borrow=True)
         Mt = B * T * St
         # xm = h + frame-position emb;  xm = ff_in(norm_in(xm)) + xm
         xm = self._ln_ff(h, tp + ".norm_in", tp + ".ff_in", Mt, C, addvec=self._pos_emb(p, C, B, T), addvec_rows_per_group=St)
@@ -372,7 +380,8 @@ class UNetRuntime:
         h = self._ln_ff(xm, tp + ".norm3", tp + ".ff", Mt, C, a1=a1_all[i], R2=h, a2=a_all[i], rows_per_group=St)
         if sp is not None:
             h = sp.space_to_frames(h, B, S)
-        return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x)
+        # (proj_out + x_in: + the partial sums of the result for the next ResBlock's in_layers.0)
+        return ops.gemm(h, W[p + ".proj_out.w"], M=M, N=C, K=C, bias=W[p + ".proj_out.b"], R1=x, gn=(F_, S) if sp is None else (0, 0))
 
     def _ln_ff(self, x, nkey, fkey, M, C, addvec=None, addvec_rows_per_group=1, **epi):
         """x' = x [+ addvec per row group];  ff(LayerNorm(x')) + x' [blend epilogue].  Where the feed-forward is the fused
@@ -453,24 +462,34 @@ class UNetRuntime:
             return c
 
         def run(c, cur, h, layers, base, h2=None):
+            """cur["gp"] = (tensor, partial sums): the GroupNorm statistics the producer of `tensor` emitted with it (ops.gemm(...,
+            gn=)).  They live in the stream's shared GroupNorm workspace, valid until the next GroupNorm on that stream -- which is
+            the one that consumes them (every consumer below is the first GroupNorm after its producer); the identity check drops
+            them wherever the tensor was replaced in between (the joins of the two-stream step, a concat)."""
             F_c = c.F
+
+            def gp_of(t):
+                g = cur.get("gp")
+                return g[1] if g is not None and g[0] is t else None
             for j, L in enumerate(layers):
                 p = f"{base}.{j}"
                 Hc, Wc = cur["H"], cur["W"]
+                gp = None
                 if L[0] == "conv_in":
-                    h = ops.gemm(h, W["conv_in.w"], M=F_c * Hc * Wc, N=mc, K=9 * CIN_PAD, bias=W["conv_in.b"],
-                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
+                    h, gp = ops.gemm(h, W["conv_in.w"], M=F_c * Hc * Wc, N=mc, K=9 * CIN_PAD, bias=W["conv_in.b"], gn=(F_c, Hc * Wc),
+                                     conv3x3=dict(Hin=Hc, Win=Wc, Cin=CIN_PAD, Hout=Hc, Wout=Wc, stride=1, up2x=0))
                     cur["C"] = mc
                 elif L[0] == "res":
-                    h = self._res(p, h, L[1], L[2], F_c, Hc, Wc, T, c.emb, c.a1, emb_full=getattr(c, "emb_full", emb_full), x2=h2, **c.kw)
+                    h, gp = self._res(p, h, L[1], L[2], F_c, Hc, Wc, T, c.emb, c.a1, emb_full=getattr(c, "emb_full", emb_full), x2=h2,
+                                      gp_in=gp_of(h), **c.kw)
                     h2 = None
                     cur["C"] = L[2]
                 elif L[0] == "attn":
-                    h = self._transformer(p, h, L[1], F_c, Hc * Wc, T, c.cond, c.a1, c.a, **c.kw)
+                    h, gp = self._transformer(p, h, L[1], F_c, Hc * Wc, T, c.cond, c.a1, c.a, gp_in=gp_of(h), **c.kw)
                 elif L[0] == "down":
                     Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
-                    h = ops.gemm(h, W[p + ".w"], M=F_c * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"],
-                                 conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=Ho, Wout=Wo, stride=2, up2x=0))
+                    h, gp = ops.gemm(h, W[p + ".w"], M=F_c * Ho * Wo, N=L[1], K=9 * L[1], bias=W[p + ".b"], gn=(F_c, Ho * Wo),
+                                     conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=Ho, Wout=Wo, stride=2, up2x=0))
                     cur["H"], cur["W"] = Ho, Wo
                 elif L[0] == "up":
                     if self.up_phases:
@@ -482,6 +501,7 @@ class UNetRuntime:
                         h = ops.gemm(h, W[p + ".w"], M=F_c * 4 * Hc * Wc, N=L[1], K=9 * L[1], bias=W[p + ".b"],
                                      conv3x3=dict(Hin=Hc, Win=Wc, Cin=L[1], Hout=2 * Hc, Wout=2 * Wc, stride=1, up2x=1))
                     cur["H"], cur["W"] = 2 * Hc, 2 * Wc
+                cur["gp"] = None if gp is None else (h, gp)
                 if L[0] in ("res", "attn") and getattr(c, "after_layer", None) is not None:
                     c.after_layer()                  # (two-stream lag: the other half may be started here)
             return h
@@ -496,7 +516,9 @@ class UNetRuntime:
 
         def head(c, cur, h, out):
             Hc, Wc = cur["H"], cur["W"]
-            h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], c.F, Hc * Wc, mc, 1e-5)
+            g = cur.get("gp")                     # (the last block's proj_out emitted the partial sums of its output: run())
+            h = ops.groupnorm_silu(h, W["out.0.g"], W["out.0.b"], c.F, Hc * Wc, mc, 1e-5,
+                                   partials=g[1] if g is not None and g[0] is h else None)
             return ops.gemm(h, W["out.2.w"], M=c.F * Hc * Wc, N=oc, K=9 * mc, bias=W["out.2.b"], out_fp32=True, out=out,
                             conv3x3=dict(Hin=Hc, Win=Wc, Cin=mc, Hout=Hc, Wout=Wc, stride=1, up2x=0))
 

@@ -360,7 +360,11 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
 
     def _conv3d_iso(self, hpad, key, b, T, H, Wd, C, R2=None, a1=None, out=None):
         """Conv3d(C, C, 3, padding 1) of clip b: hpad [B, T + 2, H * W, C] (frames 0 and T + 1 zero) -> [T * H * W, C];
-        with R2 / a1 the tail a1 * (conv + bias) + R2 (AlphaBlender folded, see _resnet) rides the last launch."""
+        with R2 / a1 the tail a1 * (conv + bias) + R2 (AlphaBlender folded, see _resnet) rides the last launch.
+        Rounding: the partial sum over the frame taps travels between the three launches as the bf16 R1 operand (the
+        ABI's residual type), so it is rounded to bf16 TWICE more than a single fp32 accumulation over all 27 taps would be --
+        each rounding 2^-9 relative, against the 4e-2 / PSNR 35 dB bound of the `videodec_*_k3` goldens (measured with it:
+        rel <= 1.2e-2).  `video_kernel_size=3` is the reference class's default but no shipped Hi3D / SVD config uses it."""
         W, HW = self.W, H * Wd
         geo = dict(Hin=H, Win=Wd, Cin=C, Hout=H, Wout=Wd, stride=1, up2x=0)
         clip = hpad[b].reshape((T + 2) * HW, C)
@@ -376,7 +380,14 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
         q = p + ".time_stack"
         if self.iso:
             out = torch.empty_like(xs)
-            hpad = torch.zeros((B, T + 2, HW, Cout), device=xs.device, dtype=torch.bfloat16)
+            # one persistent padded clip buffer per shape: only its two border frames are zero and stay zero (the GroupNorms
+            # below overwrite frames 1 .. T in full); round 5 allocated and zero-filled all T + 2 frames in every block
+            key_ = (B, T, HW, Cout, str(xs.device), torch.cuda.current_stream().cuda_stream)   # (per stream: run_chunks alternates two)
+            hpad = self._hpad.get(key_) if hasattr(self, "_hpad") else None
+            if hpad is None:
+                if not hasattr(self, "_hpad"):
+                    self._hpad = {}
+                hpad = self._hpad[key_] = torch.zeros((B, T + 2, HW, Cout), device=xs.device, dtype=torch.bfloat16)
             a1 = W[p + ".alpha"].expand(T).contiguous()
             for b in range(B):
                 rows = slice(b * T * HW, (b + 1) * T * HW)

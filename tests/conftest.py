@@ -100,7 +100,7 @@ def _gemm_env_follows_monkeypatch(request, monkeypatch):
         yield
         return
     from hi3d_hip import ops
-    names = ("HI3D_GEMM_", "HI3D_GN_FUSED_OFF")
+    names = ("HI3D_GEMM_", "HI3D_GN_FUSED_OFF", "HI3D_GN_POST", "HI3D_CONVT_SKIP")
     set_, del_ = monkeypatch.setenv, monkeypatch.delenv
 
     def setenv(name, value, *a, **k):

@@ -575,11 +575,75 @@ def test_groupnorm_statistics_from_the_producing_conv(dev, variant, N, three_d, 
     ref = F.silu(F.group_norm(out.float().cpu().reshape(inst, P, N).permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1).reshape(M, N)
     assert relerr(fused, ref) < BF16_TOL
     assert relerr(fused, three_pass.float().cpu()) < 8e-3
-    # launches that cannot provide the sums: a residual epilogue, a ragged M, a narrow tile
-    R1 = bf(rnd((M, N), 7)).to(dev)
-    assert ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), R1=R1, **kw)[1] is None
+    # launches that cannot provide the sums: a narrow tile (a residual epilogue can since round 6: next test)
     monkeypatch.setenv("HI3D_GEMM_VARIANT", "0")
     assert ops.gemm(xt, pack_conv3x3(w, Cin).to(dev), gn=(inst, P), **kw)[1] is None
+
+
+@pytest.mark.parametrize("variant,N,kind", [(7, 320, "conv_R1"), (7, 640, "conv_R1"), (7, 1280, "dense_R1"), (7, 320, "convt_blend"),
+                                            (7, 640, "convt_blend"), (7, 320, "dense_R1"), (8, 256, "conv_R1"), (8, 512, "dense_R1")])
+def test_groupnorm_statistics_from_residual_and_blend_epilogues(dev, variant, N, kind, monkeypatch):
+    """Round 6: the producers whose epilogue ADDS something after the accumulators -- out_layers.3 + skip
+    (openaimodel.py:353-354), the time_stack blend x_s + (1 - alpha) h_t (video_model.py:77-79), proj_out + x_in
+    (attention.py:722-723) -- emit the GroupNorm partial sums of their FINAL values: the residual / blend terms are added in
+    the accumulator layout (R tiles through the wave's LDS slab) before the store loop, the sums taken from those registers by
+    the round-4 butterfly.  So the norm that reads a ResBlock's or a transformer's output (in_layers.0, the time_stack's
+    in_layers.0, SpatialTransformer.norm, out.0) skips its statistics pass.  The product is the launch without statistics up
+    to the order of two fp32 operations (checked: bit-identical or one bf16 ulp on < 0.1 % of the elements), the sums are those
+    of the fp32 values before their bf16 rounding (vs the bf16 tensor: rounding noise), bit-reproducible over repeated
+    launches; HI3D_GN_POST=0 switches the feature off."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3, pack_convt3
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", str(variant))
+    Fr, H = 8, 32
+    HW = H * H
+    M = Fr * HW                                               # 8192 rows = 32 tiles of 256
+    g, b = rnd((N,), 5).abs() + 0.5, rnd((N,), 6)
+    bias = rnd((N,), 3).to(dev)
+    R = (bf(rnd((M, N), 7)) * 1.5 + 0.25).to(dev)
+    if kind == "conv_R1":
+        Cin = 64
+        x = bf(rnd((M, Cin), 1)).to(dev)
+        w = pack_conv3x3(bf(rnd((N, Cin, 3, 3), 2, (9 * Cin) ** -0.5)).float(), Cin).to(dev)
+        kw = dict(M=M, N=N, K=9 * Cin, bias=bias, R1=R, conv3x3=dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up2x=0))
+        inst, P = 2, 4 * HW                                   # (the time_stack's 3-D norm: instance = clip)
+    elif kind == "dense_R1":
+        K = 320
+        x = bf(rnd((M, K), 1)).to(dev)
+        w = bf(rnd((N, K), 2, K ** -0.5)).to(dev)
+        kw = dict(M=M, N=N, K=K, bias=bias, R1=R)
+        inst, P = Fr, HW
+    else:
+        T, Cin = 4, N                                         # Conv3d (3,1,1) over 2 clips of 4 frames, AlphaBlender tail
+        x = bf(rnd((M, Cin), 1)).to(dev)
+        w = pack_convt3(bf(rnd((N, Cin, 3, 1, 1), 2, (3 * Cin) ** -0.5)).float()).to(dev)
+        a1 = (torch.rand(Fr, generator=torch.Generator().manual_seed(9)) * 0.8 + 0.1).to(dev)
+        kw = dict(M=M, N=N, K=3 * Cin, bias=bias, a1=a1, R2=R, rows_per_group=HW, convt3=dict(T=T, HW=HW, Cin=Cin))
+        inst, P = Fr, HW
+    out, gp = ops.gemm(x, w, gn=(inst, P), **kw)
+    assert gp is not None, "this launch was expected to emit the GroupNorm partial sums"
+    sums0 = gp[:M].clone()                                    # M / 64 blocks x 32 groups x (sum, sum of squares)
+    plain = ops.gemm(x, w, **kw)
+    ndiff = int((out != plain).sum())
+    ulp = ((out.float() - plain.float()).abs() / plain.float().abs().clamp_min(1e-30)).max().item() if ndiff else 0.0
+    fused = ops.groupnorm_silu(out, g.to(dev), b.to(dev), inst, P, N, 1e-5, partials=gp)
+    three_pass = ops.groupnorm_silu(out, g.to(dev), b.to(dev), inst, P, N, 1e-5)
+    ref = F.silu(F.group_norm(out.float().cpu().reshape(inst, P, N).permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1).reshape(M, N)
+    d3 = relerr(fused, three_pass.float().cpu())
+    print(f"gn from {kind} epilogue, N={N}: vs fp32 group_norm {relerr(fused, ref):.2e}, vs the three-pass kernel {d3:.2e}; "
+          f"product vs the launch without statistics: {ndiff} of {M * N} elements differ (max rel {ulp:.1e})")
+    assert ndiff <= 1e-3 * M * N and ulp < 8.1e-3             # (one bf16 ulp = 2^-7 relative at most)
+    assert relerr(fused, ref) < BF16_TOL and d3 < 8e-3
+    # the sums themselves against the bf16 tensor (fp64 on the host): fp32 values before rounding vs after -> rounding noise
+    o64 = out.double().cpu().reshape(M // 64, 64, 32, N // 32)
+    want = torch.stack([o64.sum((1, 3)), (o64 * o64).sum((1, 3))], -1).reshape(M // 64, 64)
+    got = sums0.double().cpu().reshape(M // 64, 64)
+    assert ((got - want).abs().max() / want.abs().max()).item() < 2e-3
+    for _ in range(20):                                       # bit-reproducible
+        _, gp2 = ops.gemm(x, w, gn=(inst, P), **kw)
+        assert torch.equal(gp2[:M], sums0)
+    monkeypatch.setenv("HI3D_GN_POST", "0")
+    assert ops.gemm(x, w, gn=(inst, P), **kw)[1] is None
 
 
 @pytest.mark.parametrize("B,S", [(2, 256), (1, 1000), (3, 33), (1, 4096), (1, 5)])

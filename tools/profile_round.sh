@@ -14,14 +14,18 @@ cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile --no-legs > $O/s2_bench_under_rocprof.log 2>&1
 DB=$(ls /tmp/prof_kt/*.db 2>/dev/null | head -1)
-[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats.csv 2> $O/s2_kernel_stats.txt
+[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats.csv $O/s2_kernel_stats.txt 2> /dev/null
 rm -rf /tmp/prof_kt
 # round 4: the default command overlaps the two CFG halves of the large levels on two streams, so the kernel durations of
 # the trace above are those of kernels SHARING the chip (their sum exceeds the step).  The same command with one stream
 # (HI3D_TWO_STREAM=0: full-batch launches, nothing concurrent) gives the per-kernel durations free of overlap.
 HI3D_TWO_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt1 -o s2 -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-profile --no-legs > $O/s2_bench_under_rocprof_one_stream.log 2>&1
 DB=$(ls /tmp/prof_kt1/*.db 2>/dev/null | head -1)
-[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats_one_stream.csv 2> $O/s2_kernel_stats_one_stream.txt
+[ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $O/s2_kernel_stats_one_stream.csv $O/s2_kernel_stats_one_stream.txt 2> /dev/null
+# (round 6: each .txt is written from its CSV's rows; a header over another file's rows -- profiles/r05_s2_kernel_stats.txt -- fails here)
+for f in s2_kernel_stats s2_kernel_stats_one_stream; do
+  python $R/tools/rocpd_summary.py --check $O/$f.txt $O/$f.csv || { echo "profile_round: $f.txt does not describe $f.csv" >&2; exit 1; }
+done
 rm -rf /tmp/prof_kt1
 rocprofv3 -L > $O/rocprof_counters.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
