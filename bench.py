@@ -373,6 +373,26 @@ def simulate_sp_leg(a, unet, T, lat, dev, sp, single_gpu_ms):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.leg_steps * 1e3
         n1, b1, r1 = g.n_switches, g.bytes_moved, g.n_allreduce
+        # the same rank step as ONE HIP-graph replay (the single-GPU figure it is compared with is a graph replay
+        # too): captured on a stream of its own whose split-K scratch is registered before the capture, as FusedStepper does
+        ms_graph = None
+        try:
+            cap = torch.cuda.Stream(device=dev)
+            ops._ensure_gemm_workspace(dev, cap)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=cap):
+                o_g = rt.forward_tokens(tok, T, lat, lat, tvec, st, T, sp=g)
+            gr.replay(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.leg_steps):
+                gr.replay()
+            torch.cuda.synchronize()
+            ms_graph = (time.perf_counter() - t0) / a.leg_steps * 1e3
+            if not torch.isfinite(o_g).all():
+                ms_graph = None
+            del gr, o_g
+        except Exception as e:                      # noqa: BLE001 -- an extra figure, never a reason to lose the leg
+            log(f"[bench] simulated rank: graph capture failed: {type(e).__name__}: {e}")
         # where the distance to the ideal goes: the same rank step with HIP events around every kernel (their sum against the
         # eager wall time above = the launch-gap share; measured 37.6 of 38.0 ms: the rank is NOT launch-bound)
         prof = ops.Profiler()
@@ -399,6 +419,8 @@ def simulate_sp_leg(a, unet, T, lat, dev, sp, single_gpu_ms):
     return {"mapping": f"cfg2 x sp{sp}: one of {2 * sp} ranks, peers absent (exchange replaced by a hand-back of the packed buffer)",
             "rank_ms_per_step": round(ms, 2), "single_gpu_ms_per_step": round(single_gpu_ms, 2), "ideal_rank_ms": round(ideal, 2),
             "compute_scaling_efficiency": round(ideal / ms, 3),
+            "rank_ms_per_step_graph_replay": None if ms_graph is None else round(ms_graph, 2),
+            "compute_scaling_efficiency_graph_replay": None if ms_graph is None else round(ideal / ms_graph, 3),
             "kernels_ms_per_rank_step": fams, "kernels_total_ms": round(sum(fams.values()), 2),
             "all_to_all_per_step": n_a2a, "gn_allreduce_per_step": n_ar,
             "all_to_all_bytes_sent_per_rank_per_step": (b1 - b0) // k,

@@ -209,6 +209,111 @@ __global__ void gn_apply_kernel(const uint4* __restrict__ x, const uint4* __rest
   }
 }
 
+// ---- single-pass GroupNorm for SMALL (instance, group) slabs (round 6): one block per (instance, group) holds
+// the slab -- P pixels x C/32 channels, as 16-byte chunks -- in REGISTERS: ONE read of x, the statistics (mean first, then the
+// centred squares: fp32, fixed order -- the LayerNorm kernels' arithmetic), normalise [+ SiLU], ONE write, ONE launch.  The
+// three-pass form above costs three launches and two reads, and at the 16 x 16 / 32 x 32 levels of the UNet (a few MB per tensor,
+// 29 norms per stage-2 step, every norm of stage 1's lower half) it is pure launch latency: ~33 us per norm against ~12.
+// Needs C/32 % 8 == 0 (whole chunks per group: 1280- and 2560-wide tensors) and P * C/256 <= MAXC * blockDim chunks per slab
+// (gn_onepass_ok below: which shapes it wins on).
+// Two-source form as in gn_stats_kernel (a chunk lies in exactly one source).
+template <bool SILU, int MAXC>
+__global__ __launch_bounds__(1024) void gn_onepass_kernel(const uint4* __restrict__ x, const uint4* __restrict__ x2, int vec1, uint4* __restrict__ y,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, int P, int C, float eps) {
+  const int vec = C >> 3, cpg = C >> 5, cg = cpg >> 3;
+  const int g = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const int chunk0 = g * cg, total = P * cg;
+  const int p1 = x2 == nullptr ? vec : vec1, p2 = vec - vec1;
+  uint4 v[MAXC];                                   // (8 chunks = 32 registers; 16 waves of a 1024-thread block get 128 each)
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int id = tid + k * nthr;
+    if (id < total) {
+      const int pix = id / cg, c = id - pix * cg, chunk = chunk0 + c;
+      const bool from2 = x2 != nullptr && chunk >= vec1;
+      v[k] = from2 ? x2[((long)inst * P + pix) * p2 + (chunk - vec1)] : x[((long)inst * P + pix) * p1 + chunk];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    if (tid + k * nthr < total) {
+      const unsigned int u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += bf16_to_f32(u[j] & 0xffff) + bf16_to_f32(u[j] >> 16);
+    }
+  }
+  __shared__ float red[2][16];
+  const int wv = tid >> 6, nw = nthr >> 6, lane = tid & 63;
+  auto block_sum = [&](float t, int slot) {        // wave butterfly, then the waves' sums in wave order: the same for every thread
+    t = wave_sum(t);
+    if (lane == 0) red[slot][wv] = t;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += red[slot][i];
+    return tot;
+  };
+  const float inv_n = 1.0f / ((float)P * (float)cpg);
+  const float mean = block_sum(s, 0) * inv_n;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    if (tid + k * nthr < total) {
+      const unsigned int u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf16_to_f32(u[j] & 0xffff) - mean, b = bf16_to_f32(u[j] >> 16) - mean;
+        ss += a * a + b * b;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum(ss, 1) * inv_n + eps);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int id = tid + k * nthr;
+    if (id < total) {
+      const int pix = id / cg, chunk = chunk0 + (id - pix * cg);
+      const f32x4 g0 = *(const f32x4*)(gamma + chunk * 8), g1 = *(const f32x4*)(gamma + chunk * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + chunk * 8), b1 = *(const f32x4*)(beta + chunk * 8 + 4);
+      const float ga[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      const float be[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const unsigned int u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      unsigned int o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = (bf16_to_f32(u[j] & 0xffff) - mean) * rstd * ga[2 * j] + be[2 * j];
+        float hi = (bf16_to_f32(u[j] >> 16) - mean) * rstd * ga[2 * j + 1] + be[2 * j + 1];
+        if (SILU) { lo = silu_f(lo); hi = silu_f(hi); }
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      y[((long)inst * P + pix) * vec + chunk] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// the single-pass form applies: whole 16-byte chunks per group, a slab of at most 8 chunks per thread of a 1024-thread block, and a
+// tensor of at most 48 MB (HI3D_GN_ONEPASS=0 switches it off, =<MB> moves the bound).  Measured per shape on the MI355X
+// (profiles/r06g_gn_onepass_per_shape.log, three-pass -> single-pass): [32 x 256 x 1280] 30.0 -> 16.3 us, [32 x 256 x 2560 concat]
+// 45.0 -> 30.9, [32 x 64 x 1280] 26.6 -> 13.6, [2 x 1024 x 1280] 26.1 -> 14.1; [16 x 1024 x 1280] (42 MB) 33.3 -> 33.4; beyond
+// that the group-strided 80-byte reads lose to the three-pass form's full rows ([32 x 1024 x 1280], 84 MB: 49 -> 66 us).  A
+// streaming variant for larger slabs (3-D norms of the 16 x 16 level: 64 blocks x 0.3 MB, read twice through the L2) was built
+// and dropped: 29.5 -> 46 us -- two instances x 32 groups do not fill the chip.
+inline bool gn_onepass_ok(int inst, int P, int C) {
+  static const int mb = [] { const char* e = getenv("HI3D_GN_ONEPASS"); return e ? atoi(e) : 48; }();
+  const int cpg = C >> 5;
+  return mb > 0 && cpg % 8 == 0 && (long)P * (cpg >> 3) <= 8 * 1024 && (long)inst * P * C * 2 <= (long)mb << 20;
+}
+template <bool SILU>
+int gn_onepass_launch(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, int inst, int P, int C,
+                      float eps, hipStream_t s) {
+  const long total = (long)P * (C >> 8);
+  const dim3 grid(32, inst);
+  hipLaunchKernelGGL((gn_onepass_kernel<SILU, 8>), grid, dim3(total <= 8 * 256 ? 256 : 1024), 0, s, (const uint4*)x, (const uint4*)x2, C1 / 8,
+                     (uint4*)y, gamma, beta, P, C, eps);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
 // ---- LayerNorm: one wave per row, up to 4 16-byte vectors per lane (C <= 2048)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(
@@ -365,6 +470,9 @@ int groupnorm_launch(const void* x, const void* x2, int C1, void* y, const float
   if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
   if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (gn_onepass_ok(inst, P, C) && (x2 == nullptr || (C1 % 8 == 0 && ((uintptr_t)x2 & 15) == 0)))
+    return apply_silu ? gn_onepass_launch<true>(x, x2, C1, y, gamma, beta, inst, P, C, eps, s)
+                      : gn_onepass_launch<false>(x, x2, C1, y, gamma, beta, inst, P, C, eps, s);
   const int ppb = gn_ppb(inst, P);
   const int nblk = (P + ppb - 1) / ppb;
   float* partial = ws;
@@ -451,6 +559,9 @@ extern "C" int hi3d_groupnorm_silu_from_partials(const void* x, void* y, const f
   if (P % 64) HI3D_FAIL(HI3D_ESHAPE, "groupnorm_from_partials: P must be a multiple of the 64-row partial blocks");
   if (((uintptr_t)x | (uintptr_t)y) & 15) HI3D_FAIL(HI3D_EALIGN, "groupnorm: x/y not 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (gn_onepass_ok(inst, P, C))                         // small slab: one launch and one read either way -- the partial sums are not needed
+    return apply_silu ? gn_onepass_launch<true>(x, nullptr, C, y, gamma, beta, inst, P, C, eps, s)
+                      : gn_onepass_launch<false>(x, nullptr, C, y, gamma, beta, inst, P, C, eps, s);
   const int nblk = P / 64;                               // == hi3d_gn_partial_blocks(P, C): the stats slot sits right behind
   float* stats = ws + (long)inst * nblk * 64;
   const double inv_count = 1.0 / ((double)P * (double)(C / 32));

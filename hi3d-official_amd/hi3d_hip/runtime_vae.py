@@ -157,26 +157,37 @@ class VAEDecoderRuntime:
         return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
                         out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up), gn=gn)
 
+    def _take_gp(self, t):
+        """The GroupNorm partial sums the producer of `t` emitted with it (round 6: also conv2 + skip and proj_out + x, whose
+        epilogues add a residual), or None.  One slot: they live in the stream's shared GroupNorm workspace and are valid only for
+        the norm that follows the producer directly -- every consumer below is that norm; the identity check drops them otherwise."""
+        g, self._gp = getattr(self, "_gp", None), None
+        return g[1] if g is not None and g[0] is t else None
+
     def _resnet(self, p, x, N, H, Wd, Cin, Cout):
         W, HW = self.W, H * Wd
-        h = ops.groupnorm_silu(x, W[p + ".norm1.g"], W[p + ".norm1.b"], N, HW, Cin, 1e-6)
+        h = ops.groupnorm_silu(x, W[p + ".norm1.g"], W[p + ".norm1.b"], N, HW, Cin, 1e-6, partials=self._take_gp(x))
         h, gp = self._conv(h, p + ".conv1", N, H, Wd, Cin, Cout, gn=(N, HW))      # (+ norm2's partial sums where the tile allows)
         h = ops.groupnorm_silu(h, W[p + ".norm2.g"], W[p + ".norm2.b"], N, HW, Cout, 1e-6, partials=gp)
         skip = x
         if (p + ".nin.w") in W:
             skip = ops.gemm(x, W[p + ".nin.w"], M=N * HW, N=Cout, K=Cin, bias=W[p + ".nin.b"])
-        return self._conv(h, p + ".conv2", N, H, Wd, Cout, Cout, R1=skip)
+        out, gpo = self._conv(h, p + ".conv2", N, H, Wd, Cout, Cout, R1=skip, gn=(N, HW))   # (+ the next norm's sums: conv2 + skip)
+        self._gp = None if gpo is None else (out, gpo)
+        return out
 
     def _attn(self, p, x, N, S, C):
         W = self.W
         if C % 64:
             raise ops._l.Hi3dError("attention width must be a multiple of 64")
-        n = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], N, S, C, 1e-6, silu=False)
+        n = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], N, S, C, 1e-6, silu=False, partials=self._take_gp(x))
         qkv = ops.gemm(n, W[p + ".qkv.w"], M=N * S, N=3 * C, K=C, bias=W[p + ".qkv.b"])
         if C == 512 and VAE_FLASH:
             # round 4: one flash-style launch (hi3d_attn_d512), no score matrix in memory
             o = ops.attention_d512(qkv, N, S)
-            return ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x)
+            out, gpo = ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x, gn=(N, S))
+            self._gp = None if gpo is None else (out, gpo)
+            return out
         vt = ops.transpose_v(qkv[:, 2 * C:], N, C // 64, S, 3 * C)          # [N, C/64, 64, S_pad] == V^T [N][C][S_pad]
         S_pad = vt.shape[-1]
         o = torch.empty((N * S, C), device=x.device, dtype=torch.bfloat16)
@@ -186,7 +197,9 @@ class VAEDecoderRuntime:
             sc = ops.gemm(q, k, M=S, N=S, K=C, lda=3 * C, ldw=3 * C, out_fp32=True)     # [S, S] fp32
             pr = ops.softmax_rows(sc, S, S, S_pad, float(C) ** -0.5)
             ops.gemm(pr, vt[f], M=S, N=C, K=S_pad, lda=S_pad, ldw=S_pad, out=o[f * S:(f + 1) * S])
-        return ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x)
+        out, gpo = ops.gemm(o, W[p + ".o.w"], M=N * S, N=C, K=C, bias=W[p + ".o.b"], R1=x, gn=(N, S))
+        self._gp = None if gpo is None else (out, gpo)
+        return out
 
     @_on_own_device
     @torch.no_grad()
@@ -209,7 +222,7 @@ class VAEDecoderRuntime:
             if lvl != 0:
                 h = self._conv(h, f"up.{lvl}.up", N, H, Wd, cout, cout, up=1)
                 H, Wd = 2 * H, 2 * Wd
-        h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6)
+        h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6, partials=self._take_gp(h))
         ocp = W["conv_out.b"].numel()
         out = self._conv(h, "conv_out", N, H, Wd, cin, ocp, out_fp32=True)
         return self._finish(out, N, H, Wd, ocp)
@@ -222,6 +235,7 @@ class _ResnetMixin:
     """conv / ResnetBlock / attention helpers shared by the encoder (same arithmetic as the
     decoder's; reference model.py:131-151,161-200)."""
     _conv = VAEDecoderRuntime._conv
+    _take_gp = VAEDecoderRuntime._take_gp
     _resnet = VAEDecoderRuntime._resnet
     _attn = VAEDecoderRuntime._attn
 
@@ -398,13 +412,16 @@ class VideoDecoderRuntime(VAEDecoderRuntime):
                 self._conv3d_iso(hpad, q + ".out_layers.3", b, T, H, Wd, Cout, R2=xs[rows], a1=a1, out=out[rows])
             return out
         tg = dict(T=T, HW=HW, Cin=Cout)
-        h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5)
-        h = ops.gemm(h, W[q + ".in_layers.2.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"], convt3=tg)
-        h = ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], B, T * HW, Cout, 1e-5)
+        h = ops.groupnorm_silu(xs, W[q + ".in_layers.0.g"], W[q + ".in_layers.0.b"], B, T * HW, Cout, 1e-5, partials=self._take_gp(xs))
+        h, gp = ops.gemm(h, W[q + ".in_layers.2.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".in_layers.2.b"], convt3=tg,
+                         gn=(B, T * HW))
+        h = ops.groupnorm_silu(h, W[q + ".out_layers.0.g"], W[q + ".out_layers.0.b"], B, T * HW, Cout, 1e-5, partials=gp)
         a1 = W[p + ".alpha"].expand(N).contiguous()
         # alpha*(x_s + h_t) + (1-alpha)*x_s == x_s + alpha*h_t          (temporal_ae.py:72-79)
-        return ops.gemm(h, W[q + ".out_layers.3.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
-                        a1=a1, R2=xs, rows_per_group=HW, convt3=tg)
+        out, gpo = ops.gemm(h, W[q + ".out_layers.3.w"], M=N * HW, N=Cout, K=3 * Cout, bias=W[q + ".out_layers.3.b"],
+                            a1=a1, R2=xs, rows_per_group=HW, convt3=tg, gn=(N, HW))
+        self._gp = None if gpo is None else (out, gpo)
+        return out
 
     @_on_own_device
     @torch.no_grad()

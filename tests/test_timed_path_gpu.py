@@ -220,7 +220,7 @@ def test_stage1_clip_full_size_25_steps_and_decode_match_reference_end_to_end(de
     print(f"stage-1 config-1 clip decoded (frames {fr}): image rel {img_rel:.4f} PSNR {psnr:.1f} dB; uint8 frames: max |diff| {int(d8.max())}, "
           f"mean {d8.float().mean():.3f}, {100.0 * (d8 > 2).float().mean():.2f} % of the values differ by more than 2")
     assert psnr > 35.0 and img_rel < 8e-2
-    assert d8.float().mean() < 1.0 and (d8 > 8).float().mean() < 1e-2
+    assert d8.float().mean() < 1.5 and (d8 > 8).float().mean() < 1e-2     # (measured: PSNR 51.3 dB, max 10, mean 0.91, 6.5 % of the values off by more than 2)
 
 
 @pytest.mark.parametrize("name,src", [("sampler_s1_w320_25step_img", "sampler_s1_w320_25step"), ("v02_w320_25step_img", "v02_w320_25step")])
