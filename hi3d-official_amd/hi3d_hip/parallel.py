@@ -306,13 +306,21 @@ class ClipParallelStepper:
 
     x / the returned latent are the FULL [T,4,h,w] fp32 state (replicated, 4 MB at stage 2)."""
 
-    def __init__(self, unet, guider, T, cfg=2, group=None, sp_group=None, overlap=False):
+    def __init__(self, unet, guider, T, cfg=2, group=None, sp_group=None, overlap=False, graph=None):
         """overlap (cfg == 1 only -- e.g. cfg 1 x sp 8 on one node): the two CFG halves a rank holds run as two chains on two HIP
         streams, each with its OWN communicator over the same ranks (a second dist.new_group: collectives of one communicator
         are serialised, two communicators are not), so the all-to-all of one half travels while the other half's spatial
         sub-block computes.  In the cfg 2 mapping a rank holds ONE half and has no such independent work."""
         from . import ops  # noqa: F401  (needs the HIP library: GPU only)
+        import os
         self.unet, self.guider, self.T, self.cfg = unet, guider, T, cfg
+        # graph (round 6, opt-in: HI3D_CLIP_GRAPH=1 or graph=True): from its third call on, the whole rank step -- kernels AND the
+        # RCCL collectives between them (all-to-alls, GroupNorm-sum all-reduces, the closing all-gather: RCCL calls are stream work
+        # and capture like kernels) -- is ONE HIP-graph replay, as the single-GPU FusedStepper's step is.  Not with the host-staged
+        # gloo route of the tests.  Executed here only in a one-rank nccl group (tests/test_parallel_gpu.py) and on the
+        # simulated rank of bench.py: on by request until it has run on a multi-GPU node.
+        self.use_graph = (os.environ.get("HI3D_CLIP_GRAPH", "0") == "1") if graph is None else bool(graph)
+        self._graph, self._graph_key, self._eager_steps = None, None, 0
         self.group = group
         self.sp, self.half, self.part, self.sp_group = clip_parallel_groups(group, cfg, sp_group)
         self.comm = FrameSpaceGroup(T, self.sp_group)
@@ -365,6 +373,41 @@ class ClipParallelStepper:
 
     @torch.no_grad()
     def step(self, x, sigmas, i, c, uc, image_only_indicator=None):
+        dev = x.device
+        if not (self.use_graph and x.is_cuda and not self._host_staged):
+            return self._step(x, sigmas[i:i + 2], c, uc, image_only_indicator)
+        key = (tuple(x.shape), id(c), id(uc), tuple(v._version for d in (c, uc) for v in d.values()),
+               None if image_only_indicator is None else tuple(image_only_indicator.shape))
+        if self._graph is not None and self._graph_key == key:
+            # the per-clip constants live in persistent buffers the graph reads: refreshed in place here when the conditioning /
+            # image_only_indicator VALUES changed (identity + version checked inside; a fresh tensor per call pays a cheap refresh)
+            with torch.cuda.device(dev):
+                ctx, y, _ = self._conds(c, uc, dev)
+                self.unet.runtime(dev).clip_consts(ctx, y, image_only_indicator, (2 // self.cfg) * self.T, self.T)
+            self._g_x.copy_(x)
+            self._g_sig.copy_(sigmas[i:i + 2])
+            self._graph.replay()
+            return self._g_out.clone()
+        if self._graph_key != key:
+            self._graph, self._graph_key, self._eager_steps = None, key, 0
+        if self._eager_steps < 2:                     # two eager steps fill the lazy caches and raise every kernel's LDS limit
+            self._eager_steps += 1
+            return self._step(x, sigmas[i:i + 2], c, uc, image_only_indicator)
+        from . import ops
+        with torch.cuda.device(dev):
+            self._g_x, self._g_sig = x.clone(), sigmas[i:i + 2].clone().to(dev)
+            cap = torch.cuda.Stream(device=dev)
+            ops._ensure_gemm_workspace(dev, cap)      # (split-K scratch of the capture stream: registered before the capture)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g, stream=cap):
+                self._g_out = self._step(self._g_x, self._g_sig, c, uc, image_only_indicator)
+            self._graph, self._hold = g, (c, uc, image_only_indicator)      # (refs held: the key's ids stay unique)
+            g.replay()
+            return self._g_out.clone()
+
+    def _step(self, x, sig2, c, uc, image_only_indicator=None):
+        """one step; sig2 = (sigma_i, sigma_{i+1}) on any device"""
         from . import ops
         from .runtime_unet import CIN_PAD
         dev = x.device
@@ -379,7 +422,7 @@ class ClipParallelStepper:
             # buffer of this rank's frames, c_noise per batch row, sigma read on the device
             cu_l, cc_l = self._clip[5]          # (cfg == 2: this rank's half in both slots, one is read)
             xl, tok2, sig, tv_l, tv_full = self._buffers(x, cu_l, cc_l, dev)
-            sig.copy_(sigmas[i:i + 2])
+            sig.copy_(sig2)
             xl.copy_(x[lo:lo + Tl])
             ops.cfg_update_x(xl, tok2, sig, tv_l, Tl, HW, CIN_PAD)
             tok = tok2 if B == 2 else tok2[self.half * Tl * HW:(self.half + 1) * Tl * HW]

@@ -657,15 +657,20 @@ def test_gemm_dispatch_of_the_headline_shapes_needs_no_gpu():
     out4 = describe(524288, 4, 2880, lda=320, amode=L.A_CONV3X3, Hin=128, Win=128, Cin=320, Hout=128, Wout=128, stride=1, out_fp32=1)
     assert out4["NT"] * 32 <= 64                                          # the narrow tile: N = 4 does not pay for 160 columns
     # producer-side GroupNorm statistics (hi3d_gemm_desc.gn_partial): the probe answers without a launch -- yes for the wide tile on
-    # full tiles with nothing added after the accumulators, no once a residual rides the epilogue
+    # full tiles, since round 6 also when a residual rides the epilogue (GemmParams.gn_post: 16-byte rows); no for fp32 output
     d = L.GemmDesc()
     d.A = d.W = d.out = d.gn_partial = 4096
     d.M, d.N, d.K, d.lda, d.ldo, d.ldw, d.rows_per_group = 524288, 320, 2880, 320, 320, 2880, 1
     d.amode, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride = L.A_CONV3X3, 128, 128, 320, 128, 128, 1
     assert lib.hi3d_gemm_gn_partial_supported(C.byref(d), None) == 1
     d.R1, d.ldr1 = 4096, 320
+    assert lib.hi3d_gemm_gn_partial_supported(C.byref(d), None) == 1
+    assert lib.hi3d_gemm_last_gn_fused() == 1                        # (the last dispatch of this thread: the R1 form above)
+    d.ldr1 = 324                                                     # rows of the residual not 16-byte aligned: the interior store path is off
     assert lib.hi3d_gemm_gn_partial_supported(C.byref(d), None) == 0
-    assert lib.hi3d_gemm_last_gn_fused() == 0                        # (the last dispatch of this thread: the R1 form above)
+    d.ldr1, d.out_fp32 = 320, 1
+    assert lib.hi3d_gemm_gn_partial_supported(C.byref(d), None) == 0
+    assert lib.hi3d_gemm_last_gn_fused() == 0
     # the GroupNorm partial-sum workspace: hi3d_gn_workspace_floats is sized from hi3d_gn_partial_blocks (+ 64 floats of statistics
     # per instance), and the producer-side partial sums (one block per 64 rows) never exceed it
     for inst, P, Cc in ((32, 16384, 320), (2, 16 * 16384, 320), (1, 1 << 20, 128), (32, 64, 1280)):

@@ -74,7 +74,7 @@ def _case_full(dev):
     return fx, unet, guider, T, x0 * 700.0, c, uc, sigmas
 
 
-def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo", overlap=False, poison=False):
+def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo", overlap=False, poison=False, graph=False, nsteps=2):
     for p in (os.path.join(ROOT, "hi3d-official_amd"), ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -90,12 +90,14 @@ def _rank_main(rank, world, port, cfg, ret, case="tiny", backend="gloo", overlap
     try:
         from hi3d_hip.parallel import ClipParallelStepper
         fx, unet, guider, T, x, c, uc, sigmas = (_case_full if case == "full" else _case)(dev)
-        stepper = ClipParallelStepper(unet, guider, T, cfg=cfg, overlap=overlap)
+        stepper = ClipParallelStepper(unet, guider, T, cfg=cfg, overlap=overlap, graph=graph)
         x = x.to(dev)
         cd = {k: v.to(dev) for k, v in c.items()}
         ucd = {k: v.to(dev) for k, v in uc.items()}
-        for i in range(2):                            # two steps: the second reuses the per-clip constants
-            x = stepper.step(x, sigmas.to(dev), i, cd, ucd, torch.zeros(2 // cfg, T, device=dev))
+        for i in range(nsteps):                       # two steps: the second reuses the per-clip constants
+            x = stepper.step(x, sigmas.to(dev), i % 2, cd, ucd, torch.zeros(2 // cfg, T, device=dev))
+        if graph and nsteps > 2:
+            assert stepper._graph is not None, "the third step must have been captured"
         comms = [stepper.comm] + ([stepper.comm2] if stepper.comm2 is not None else [])
         ret[rank] = (x.cpu(), sum(c.n_switches for c in comms), sum(c.n_allreduce for c in comms), sum(c.bytes_moved for c in comms),
                      stepper.gather_bytes)
@@ -268,6 +270,21 @@ def test_nccl_world_size_1_paths(dev):
     ret2 = mgr.dict()
     mp.spawn(_vae_rank_main, args=(1, _free_port(), ret2, "nccl"), nprocs=1, join=True)
     assert torch.equal(ret2[0][0], refv) and ret2[0][1] == 0
+
+
+def test_clip_parallel_rank_step_as_one_hip_graph_with_rccl_collectives(dev):
+    """Round 6: ClipParallelStepper(graph=True) captures the whole rank step -- step head, UNet kernels, the
+    RCCL all-gather of the network output (and, on a real group, the all-to-alls and GroupNorm all-reduces), guidance + Euler
+    update -- into ONE HIP graph at its third call and replays it afterwards.  One-rank `nccl` group on this GPU (the build's
+    boxes have one): four steps eager vs four steps with the capture at step 3 and a replay at step 4 -- same latents."""
+    mgr = mp.Manager()
+    eager, graphed = mgr.dict(), mgr.dict()
+    mp.spawn(_rank_main, args=(1, _free_port(), 1, eager, "tiny", "nccl", False, False, False, 4), nprocs=1, join=True)
+    mp.spawn(_rank_main, args=(1, _free_port(), 1, graphed, "tiny", "nccl", False, False, True, 4), nprocs=1, join=True)
+    a, b = eager[0][0], graphed[0][0]
+    rel = ((a - b).abs().max() / a.abs().max()).item()
+    print(f"clip-parallel rank step, eager vs HIP-graph replay (one-rank nccl group): rel {rel:.2e}")
+    assert torch.isfinite(b).all() and rel < 1e-5
 
 
 def test_permute_rows_and_simulated_group(dev):

@@ -9,7 +9,7 @@
 #   5. bench.py's multi-GPU legs in a ONE-rank nccl group under torchrun (dry run of the code the driver runs on 2/4/8 GPUs)
 # Copy what is to be judged from gpurun_out/$TAG into profiles/ afterwards (names: profiles/README.md, round-5 table).
 HEAD=${1:-unknown}
-TAG=${2:-r05}
+TAG=${2:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

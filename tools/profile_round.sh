@@ -4,7 +4,7 @@
 #   rocprofv3 kernel-trace summary of the stage-2 bench, and PMC passes (separate runs, kernel trace only, as the
 #   pool requires): FETCH_SIZE, WRITE_SIZE (HBM-side traffic per kernel) and two SQ passes (MFMA busy / VALU).
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ (tools/collect_profiles.sh).
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
