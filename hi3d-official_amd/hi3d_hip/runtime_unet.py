@@ -437,7 +437,11 @@ class UNetRuntime:
         cond, a_all, a1_all = st["cond"], st["a_all"], st["a1_all"]
         emb_full = emb_all
         if sp is not None and sp.world > 1:
-            idx = sp.local_frames(B_all).to(self.dev)
+            # (device copy of the rank's frame indices cached: a host-to-device copy per call is also not capturable into a HIP graph)
+            ikey = ("local_frames", sp.T, sp.world, sp.rank, B_all)
+            idx = self._pos_cache.get(ikey)
+            if idx is None:
+                idx = self._pos_cache[ikey] = sp.local_frames(B_all).to(self.dev)
             emb_all = emb_full.index_select(0, idx)                 # rows of this GPU's frames (spatial sub-blocks)
             cond = dict(cond)
             for pt, _ in self.transformers:                          # per-frame vectors of the spatial blocks

@@ -241,6 +241,71 @@ def gen_sampler_at_size(name, cfg, T, hw, steps, n_run, max_scale, stage, wseed=
     print(f"{name}: {n_run} steps, mean {sum(step_s) / len(step_s):.1f}s/step, total {time.time() - t0:.0f}s", flush=True)
 
 
+def gen_v02_at_size(name, cfg, T, hw, steps, max_scale, keep, wseed=1, iseed=0, decode_frames=None):
+    """BASELINE config 3 end to end on the reference classes: the stage-2 refine loop of pipeline_i2v_eval_v02.py:103-135 (re-noising
+    blend alpha_i = (0.5 (1 + cos(i / 25)))^40 with the per-frame encoded latents, then EulerEDMSampler.step_call with CFG 1 -> 2)
+    at its REAL size -- 16 views, latent 128 x 128, 17 input channels, all 25 steps (~10 min per step on 8 cores, ~45 GB) -- then
+    the reference's decode + tensor2vid of `decode_frames`.  Stored: the guided denoised estimate D_i (fp16) of the steps in `keep`,
+    the final latents (fp32), the decoded frames; inputs re-drawn from `input_seed` (init / c / uc: synth.synth_conditioning;
+    z frames: N(0, 0.8^2) from seed + 100, as gen_v02)."""
+    import math
+    t0 = time.time()
+    threads = torch.get_num_threads()
+    unet = build_unet(cfg, wseed)
+    sampler, denoiser = _ref_sampler(unet, T, steps, max_scale)
+    append_dims = ref_import.ref("sgm.util.append_dims")
+    init, c, uc = synth.synth_conditioning(T, hw, hw, stage=2, seed=iseed, adm_in=cfg["adm_in_channels"])
+    g = torch.Generator().manual_seed(iseed + 100)
+    z_list = [torch.randn((1, 4, hw, hw), generator=g) * 0.8 for _ in range(T)]
+    Ds, step_s, kept = [], [], {}
+    ref_denoise = sampler.denoise
+
+    def recording_denoise(*a, **k):
+        d = ref_denoise(*a, **k)
+        Ds.append(d)
+        return d
+    sampler.denoise = recording_denoise
+    with torch.no_grad():
+        sigmas = sampler.discretization(sampler.num_steps, device="cpu")
+        num_sigmas = len(sigmas)
+        s_in = init.new_ones([T])
+        latents = init.clone()
+        latents *= torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        z = z_list[0]
+        for i in sampler.get_sigma_gen(num_sigmas):
+            t1 = time.time()
+            alpha = math.pow(0.5 * (1 + math.cos(i * 1.0 / sampler.num_steps)), 40.0)
+            for t in range(T):
+                latents[t:t + 1] = latents[t:t + 1] * (1 - alpha) + (init[t:t + 1] * append_dims(sigmas[i], z.ndim) + z_list[t]) * alpha
+            latents = sampler.step_call(denoiser, latents, i, s_in, sigmas, num_sigmas, c, uc)
+            step_s.append(time.time() - t1)
+            if i in keep:
+                kept[i] = Ds[-1].to(torch.float16)
+            Ds.clear()
+            print(f"{name}: step {i} {step_s[-1]:.1f}s |x| {latents.abs().max():.3f}", flush=True)
+            # (partial fixture after every step: a 4-hour job that is cut short still leaves what it finished)
+            torch.save(dict(kind="v02_at_size_partial", steps_done=i + 1, kept_steps=sorted(kept), ref_step_seconds=list(step_s)),
+                       os.path.join(GOLD, name + ".partial.pt"))
+    fx = dict(kind="v02_at_size", cfg=cfg, T=T, hw=hw, steps=steps, max_scale=max_scale, weight_seed=wseed, key_prefix=UNET_PREFIX,
+              input_seed=iseed, init_probe=dict(head=init.flatten()[:16].clone(), sum=float(init.double().sum()),
+                                                abs_sum=float(init.double().abs().sum())),
+              z_probe=dict(head=z_list[0].flatten()[:16].clone(), sum=float(torch.cat(z_list).double().sum())),
+              sigmas=sigmas, kept_steps=sorted(kept), denoised_f16=torch.stack([kept[i] for i in sorted(kept)]),
+              output=latents.clone(), ref_step_seconds=step_s, ref_host=_host_facts(threads),
+              shapes_sha256=shapes_digest(unet.state_dict()))
+    if decode_frames:
+        del unet
+        t1 = time.time()
+        img, vid = _ref_decode_frames(latents, decode_frames)
+        fx.update(decode_frames=list(decode_frames), decoded_f16=img.to(torch.float16), decoded_u8=vid, ref_decode_seconds=time.time() - t1)
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+    try:
+        os.remove(os.path.join(GOLD, name + ".partial.pt"))
+    except OSError:
+        pass
+    print(f"{name}: {steps} steps, mean {sum(step_s) / len(step_s):.1f}s/step, total {time.time() - t0:.0f}s", flush=True)
+
+
 def gen_decode_of(name, src, ch=128):
     """Full-width end-to-end image golden: the REFERENCE's decode_first_stage + tensor2vid of the final latents an existing
     reference-class sampler fixture holds (`src`.output) -- sample -> decode -> uint8 frames all from reference classes."""
@@ -474,6 +539,10 @@ def main():
         jobs["sampler_s1_full_25step"] = lambda: gen_sampler_at_size("sampler_s1_full_25step", unet_cfg(1), T=16, hw=64, steps=25, n_run=25,
                                                                      max_scale=2.5, stage=1, iseed=32,
                                                                      decode_frames=(0, 5, 10, 15))
+        # BASELINE config 3 exactly, end to end: the stage-2 refine loop, 16 views, latent 128 x 128, all 25 steps (~4 h on 8 cores,
+        # ~45 GB), the reference decode + tensor2vid of frames 0 and 8
+        jobs["v02_s2_full_25step"] = lambda: gen_v02_at_size("v02_s2_full_25step", unet_cfg(2), T=16, hw=128, steps=25, max_scale=2.0,
+                                                             keep=(0, 1, 2, 6, 12, 18, 24), iseed=41, decode_frames=(0, 8))
         # reference decode + tensor2vid of the final latents of the two full-width 25-step fixtures (4 frames of 128 x 128)
         jobs["sampler_s1_w320_25step_img"] = lambda: gen_decode_of("sampler_s1_w320_25step_img", "sampler_s1_w320_25step")
         jobs["v02_w320_25step_img"] = lambda: gen_decode_of("v02_w320_25step_img", "v02_w320_25step")

@@ -43,7 +43,8 @@ ROW_TESTS = [
         "test_vae_gpu.py::test_cond_frame_embedder_matches_reference_encoder"]),
     ("a18 v02 blend loop", [
         "test_unet_gpu.py::test_stage2_refine_loop_matches_reference_golden",
-        "test_at_size_gpu.py::test_stage2_refine_25_steps_full_width_matches_reference_golden"]),
+        "test_at_size_gpu.py::test_stage2_refine_25_steps_full_width_matches_reference_golden",
+        "test_timed_path_gpu.py::test_stage2_refine_loop_full_size_25_steps_and_decode_match_reference_end_to_end"]),
     ("a20 / f1 VideoDecoder, AE3DConv", ["test_vae_gpu.py::test_video_decoder"]),
     ("b boundary: torch.ops.hi3d, error convention", ["test_torch_ops_gpu.py::", "test_kernels_gpu.py::test_errors_are_loud"]),
     ("e multi-GPU: CFG split, frame<->space all-to-all, sharded decode", ["test_parallel_gpu.py::"]),

@@ -304,3 +304,37 @@ def test_permute_rows_and_simulated_group(dev):
     assert sp.shape == (B * 8 * (S // 4), C)
     back = g.space_to_frames(sp, B, S)
     assert back.shape == t.shape and g.n_switches == 2
+
+
+def test_sharded_rank_forward_is_graph_capturable(dev):
+    """What a rank of a REAL frame <-> space group issues between its collectives -- the per-rank index selections, the pack /
+    unpack kernels, the partial-sum GroupNorms -- must not contain anything a HIP-graph capture rejects (round 6: the first
+    capture attempt of bench.py's simulated rank died on a host-to-device copy of the rank's frame indices, made per call).
+    One rank of a 2-way group without peers (SimulatedFrameSpaceGroup): two eager passes, then capture + replay == eager."""
+    from hi3d_hip import ops
+    from hi3d_hip.parallel import SimulatedFrameSpaceGroup
+    from hi3d_hip.runtime_unet import CIN_PAD
+    fx, unet, guider, T, x, c, uc, sigmas = _case(dev)
+    rt = unet.runtime(dev)
+    g = SimulatedFrameSpaceGroup(T, 2)
+    lat = 16
+    gen = torch.Generator(device=dev).manual_seed(3)
+    tok = torch.randn((g.Tl * lat * lat, CIN_PAD), device=dev, generator=gen).to(torch.bfloat16)
+    tok[:, fx["cfg"]["in_channels"]:] = 0
+    tvec = torch.full((T,), 0.3, device=dev)
+    ctx = torch.randn((1, 1, fx["cfg"]["context_dim"]), device=dev, generator=gen)
+    y = torch.randn((1, fx["cfg"]["adm_in_channels"]), device=dev, generator=gen)
+    with torch.no_grad():
+        st = rt.clip_consts(ctx, y, torch.zeros(1, T, device=dev), T, T)
+        for _ in range(2):
+            ref = rt.forward_tokens(tok, T, lat, lat, tvec, st, T, sp=g).clone()
+        cap = torch.cuda.Stream(device=dev)
+        ops._ensure_gemm_workspace(dev, cap)
+        gr = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gr, stream=cap):
+            out = rt.forward_tokens(tok, T, lat, lat, tvec, st, T, sp=g)
+        for _ in range(2):
+            gr.replay()
+        torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, ref)

@@ -243,3 +243,75 @@ def test_full_width_25_step_latents_decode_to_the_reference_images(dev, name, sr
     d8 = (torch.stack([torch.from_numpy(f) for f in frames]).int() - fx["decoded_u8"].int()).abs()
     print(f"{name}: image rel {relerr(img, ref):.4f} PSNR {psnr:.1f} dB; uint8 max |diff| {int(d8.max())} mean {d8.float().mean():.3f}")
     assert relerr(img, ref) < 4e-2 and psnr > 35.0 and int(d8.max()) <= 8 and d8.float().mean() < 1.0      # (measured: max 5, mean 0.52 -- astype(uint8) truncates, so sub-LSB differences flip values)
+
+
+def test_stage2_refine_loop_full_size_25_steps_and_decode_match_reference_end_to_end(dev):
+    """BASELINE config 3 exactly, end to end from reference classes: the stage-2 refine loop of pipeline_i2v_eval_v02.py:103-135
+    -- re-noising blend with the per-frame latents, Euler-EDM, CFG 1 -> 2 -- at 16 views, latent 128 x 128, all 25 steps, through
+    the product loop (hi3d_v02_blend + the fused graph-replayed two-stream step), then decode_first_stage one frame per call
+    (en_and_decode_n_samples_a_time = 1) and tensor2vid, against `v02_s2_full_25step` (oracle/gen_golden.py: ~4 h of the reference
+    on 8 cores).  The guided denoised estimate of the kept steps, the final latents, the decoded frames."""
+    from conftest import synth_fill_cached, synth_unet
+    from hi3d_hip import ops, synth
+    from hi3d_hip.pipelines import v02_alpha
+    from sgm.models.autoencoder import AutoencoderKL
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    from vtdm.util import tensor2vid
+    fx = load("v02_s2_full_25step")
+    T, hw, steps = fx["T"], fx["hw"], fx["steps"]
+    assert (T, hw, steps, fx["max_scale"]) == (16, 128, 25, 2.0)
+    init, c, uc = synth.synth_conditioning(T, hw, hw, stage=2, seed=fx["input_seed"], adm_in=fx["cfg"]["adm_in_channels"])
+    pr = fx["init_probe"]
+    assert torch.equal(init.flatten()[:16], pr["head"]) and abs(float(init.double().sum()) - pr["sum"]) < 1e-6 * pr["abs_sum"]
+    g = torch.Generator().manual_seed(fx["input_seed"] + 100)
+    z_frames = torch.cat([torch.randn((1, 4, hw, hw), generator=g) * 0.8 for _ in range(T)], 0)
+    assert torch.equal(z_frames[0].flatten()[:16], fx["z_probe"]["head"])
+    unet = synth_unet(dict(fx, stage=2), dev)
+    rt = unet.runtime(dev)
+    model = OpenAIWrapper(unet)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    sampler = make_sampler(dict(fx, stage=2), dev)
+    cd, ucd = {k: v.to(dev) for k, v in c.items()}, {k: v.to(dev) for k, v in uc.items()}
+    extra = dict(image_only_indicator=torch.zeros(2, T, device=dev), num_video_frames=T)
+
+    def denoiser(inp, sigma, cc):
+        return den(model, inp, sigma, cc, **extra)
+
+    sigmas = sampler.discretization(sampler.num_steps, device=dev)
+    sig_host = sigmas.float().cpu().tolist()
+    num_sigmas = len(sigmas)
+    initd, zd = init.to(dev).contiguous(), z_frames.to(dev).contiguous()
+    latents = (initd * math.sqrt(1.0 + sig_host[0] ** 2)).contiguous()
+    s_in = latents.new_ones([T])
+    kept = {k: n for n, k in enumerate(fx["kept_steps"])}
+    worst = (0.0, 1.0)
+    for i in sampler.get_sigma_gen(num_sigmas):
+        ops.v02_blend(latents, initd, zd, v02_alpha(i, sampler.num_steps), sig_host[i])          # v02.py:127-131
+        x_next = sampler.step_call(denoiser, latents, i, s_in, sigmas, num_sigmas, cd, ucd).contiguous()
+        if i in kept:
+            D, ref_D = denoised_from_states(latents, x_next, sigmas, i), fx["denoised_f16"][kept[i]].float()
+            rel, cs = relerr(D, ref_D), cos(D, ref_D)
+            worst = (max(worst[0], rel), min(worst[1], cs))
+            print(f"stage-2 refine loop at full size, step {i}: denoised rel {rel:.4f} cos {cs:.6f}")
+            assert rel < D_TOL and cs > D_COS, f"step {i}: denoised rel {rel:.4f} cos {cs:.6f}"
+        latents = x_next
+    assert rt.steppers[(T, hw, hw)].graph is not None and rt.last_forward_two_stream
+    lat_rel, lat_cos = relerr(latents, fx["output"]), cos(latents, fx["output"])
+    print(f"stage-2 refine loop at full size (config 3), 25 steps: worst denoised rel {worst[0]:.4f} cos {worst[1]:.6f}; "
+          f"final latents rel {lat_rel:.4f} cos {lat_cos:.6f}")
+    assert lat_rel < D_TOL and lat_cos > 0.999
+    # ---- decode_first_stage (one frame per call) -> tensor2vid, frames of the fixture
+    ae = AutoencoderKL(embed_dim=4, ddconfig=dict(attn_type="vanilla-xformers", double_z=True, z_channels=4, resolution=256, in_channels=3,
+                                                  out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0),
+                       lossconfig={"target": "torch.nn.Identity"}).to(dev)
+    synth_fill_cached(ae, "first_stage_model.", 1, dev)
+    fr = fx["decode_frames"]
+    img = torch.cat([ae.decode(latents[f:f + 1] / 0.18215) for f in fr], 0).float().cpu()
+    ref_img = fx["decoded_f16"].float()
+    psnr = 10 * math.log10(ref_img.abs().max().item() ** 2 / ((img - ref_img) ** 2).mean().item())
+    frames = tensor2vid(img.reshape(1, len(fr), *img.shape[1:]).permute(0, 2, 1, 3, 4).clone())
+    d8 = (torch.stack([torch.from_numpy(f) for f in frames]).int() - fx["decoded_u8"].int()).abs()
+    print(f"stage-2 refine loop at full size decoded (frames {fr} at 1024 x 1024): image rel {relerr(img, ref_img):.4f} PSNR {psnr:.1f} dB; "
+          f"uint8 max |diff| {int(d8.max())}, mean {d8.float().mean():.3f}")
+    assert psnr > 35.0 and d8.float().mean() < 1.5 and (d8 > 8).float().mean() < 1e-2

@@ -5,7 +5,7 @@
 # and the per-family kernel times of the eager profile pass.
 OUT=$1; shift
 : > $OUT
-for rep in 1 2; do
+for rep in $(seq 1 ${AB_REPS:-2}); do
   for spec in "$@"; do
     label=${spec%%:*}; envs=${spec#*:}
     ( IFS=';'; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done
