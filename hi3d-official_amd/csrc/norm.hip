@@ -544,6 +544,29 @@ extern "C" int hi3d_groupnorm_fold_linear(const void* x, float* ws, const float*
   return HI3D_OK;
 }
 
+// ... with the partial sums of x already in ws (the producer of x emitted them: hi3d_gemm_desc.gn_partial, 64-row blocks): finalize
+// + fold only -- x itself is not read at all by the norm (round 6)
+extern "C" int hi3d_groupnorm_fold_linear_from_partials(float* ws, const float* gamma, const float* beta, float eps,
+                                                        int32_t inst, int32_t P, int32_t C, const void* W, int32_t ldw,
+                                                        const float* bias, int32_t N, void* Wf, float* biasf, void* stream) {
+  if (!ws || !gamma || !beta || !W || !Wf || !biasf) HI3D_FAIL(HI3D_EINVAL, "groupnorm_fold_linear: null pointer");
+  if (inst <= 0 || P <= 0 || C <= 0 || N <= 0) HI3D_FAIL(HI3D_EINVAL, "groupnorm_fold_linear: non-positive size");
+  if (C % 32 || C > 8192) HI3D_FAIL(HI3D_ESHAPE, "groupnorm: C must be a multiple of 32 (<= 8192)");
+  if (P % 64) HI3D_FAIL(HI3D_ESHAPE, "groupnorm_fold_linear_from_partials: P must be a multiple of the 64-row partial blocks");
+  if (ldw < C || ldw % 2) HI3D_FAIL(HI3D_EALIGN, "groupnorm_fold_linear: ldw < C or odd");
+  if (((uintptr_t)W & 3) || ((uintptr_t)Wf & 15)) HI3D_FAIL(HI3D_EALIGN, "groupnorm_fold_linear: misaligned pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = P / 64;
+  float* stats = ws + (long)inst * nblk * 64;
+  const double inv_count = 1.0 / ((double)P * (double)(C / 32));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, inst), dim3(256), 0, s, ws, stats, nblk, inv_count, eps);
+  HI3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(N, inst), dim3(64), 0, s, (const unsigned short*)W, ldw, bias, gamma, beta, stats,
+                     (unsigned short*)Wf, biasf, C, N);
+  HI3D_LAUNCH_CHECK();
+  return HI3D_OK;
+}
+
 extern "C" int hi3d_groupnorm_silu(const void* x, void* y, const float* gamma, const float* beta,
                                    float* ws, int32_t inst, int32_t P, int32_t C, float eps,
                                    int32_t apply_silu, void* stream) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "hi3d_gn_workspace_floats", "hi3d_groupnorm_silu", "hi3d_groupnorm_silu_cat2", "hi3d_groupnorm_silu_from_partials", "hi3d_gemm_gn_partial_supported", "hi3d_gemm_last_gn_fused", "hi3d_groupnorm_partial_sums", "hi3d_groupnorm_apply_sums", "hi3d_layernorm",
     "hi3d_concat_channels", "hi3d_timestep_embedding", "hi3d_silu_f32_to_bf16",
     "hi3d_cfg_prepare", "hi3d_sampler_step", "hi3d_cfg_update_x", "hi3d_sampler_step_dev", "hi3d_nchw_f32_to_nhwc_bf16",
-    "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows", "hi3d_vae_posterior", "hi3d_v02_blend", "hi3d_time_mix_small", "hi3d_time_mix_small_k3", "hi3d_ffn_geglu", "hi3d_ffn_geglu_ln", "hi3d_groupnorm_fold_linear",
+    "hi3d_nhwc_to_nchw_f32", "hi3d_vae_latent_prepare", "hi3d_softmax_rows", "hi3d_vae_posterior", "hi3d_v02_blend", "hi3d_time_mix_small", "hi3d_time_mix_small_k3", "hi3d_ffn_geglu", "hi3d_ffn_geglu_ln", "hi3d_groupnorm_fold_linear", "hi3d_groupnorm_fold_linear_from_partials",
     "hi3d_act_bf16", "hi3d_l2_normalize_rows", "hi3d_add_act_bf16", "hi3d_dpt_stem_conv", "hi3d_pool2_nhwc",
     "hi3d_resize_bilinear_nhwc", "hi3d_dpt_head_out", "hi3d_depth_normalize_unshuffle", "hi3d_resample_axis", "hi3d_permute_rows",
 ]
@@ -111,6 +111,7 @@ def load():
         "hi3d_time_mix_small_k3": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "hi3d_ffn_geglu": (C.c_int, [vp] * 10 + [i32] * 7 + [vp]),
         "hi3d_groupnorm_fold_linear": (C.c_int, [vp] * 4 + [C.c_float] + [i32] * 3 + [vp, i32, vp, i32, vp, vp, vp]),
+        "hi3d_groupnorm_fold_linear_from_partials": (C.c_int, [vp] * 3 + [C.c_float] + [i32] * 3 + [vp, i32, vp, i32, vp, vp, vp]),
         "hi3d_ffn_geglu_ln": (C.c_int, [vp] * 3 + [C.c_float, vp, i32] + [vp] * 9 + [i32] * 7 + [vp]),
         "hi3d_act_bf16": (C.c_int, [vp, i64, i32, vp]),
         "hi3d_l2_normalize_rows": (C.c_int, [vp, i32, i32, vp]),

@@ -414,24 +414,31 @@ def groupnorm_silu_sharded(x, gamma, beta, inst, P, C, eps, allreduce_, world, s
 
 # HI3D_GN_FOLD=1: the transformer's GroupNorm as a per-frame rescaling of proj_in's weights.  Opt-in: it removes the norm's apply
 # pass (GroupNorm family 9.85 -> 9.40 ms per stage-2 step) but the step's wall time does not move (198.96 / 198.69 vs 198.49 /
-# 199.12 ms: those passes already ran under the other CFG half's matrix-core kernels) -- profiles/r04s_gn_fold_ab.log
+# 199.12 ms: those passes already ran under the other CFG half's matrix-core kernels) -- profiles/r04s_gn_fold_ab.log.  Round 6:
+# with the statistics from the producer's partial sums the norm reads no activation at all (GroupNorm family 8.48 -> 8.02 ms) --
+# and the step still does not move (194.78 vs 194.81 ms over three alternations, profiles/r06k_ab_gn_fold_from_partials.log).
 GN_FOLD = os.environ.get("HI3D_GN_FOLD", "0") == "1"
 
 
-def groupnorm_fold_linear(x, gamma, beta, inst, P, C, eps, W, bias, N):
+def groupnorm_fold_linear(x, gamma, beta, inst, P, C, eps, W, bias, N, partials=None):
     """The statistics of GroupNorm(32; no activation) over x [inst * P, C] folded into the linear layer (W [N, C] bf16 K-major,
     bias [N] fp32 or None) that consumes the normalised tensor: returns (Wf [inst, N, C] bf16, biasf [inst, N] fp32) for
     gemm(x, Wf, ..., rowvec=biasf, rows_per_group=P, w_group_stride=N * C).  See include/hi3d_hip.h.
+    partials: the workspace in which the producer of x left its partial sums (gemm(..., gn=)): x is then not read at all.
     Reference: SpatialTransformer.norm + proj_in, sgm/modules/attention.py:702-712."""
     _chk_dev(x, gamma, beta, W, bias)
     assert W.dtype == torch.bfloat16 and W.is_contiguous() and W.shape[-1] == C and W.shape[0] == N
-    ws = _gn_workspace(x.device, inst, P, C)
+    ws = _gn_workspace(x.device, inst, P, C) if partials is None else partials
     Wf = torch.empty((inst, N, C), device=x.device, dtype=torch.bfloat16)
     biasf = torch.empty((inst, N), device=x.device, dtype=torch.float32)
     prof = PROFILER
     t0 = prof.begin() if prof else None
-    _l.check(_lib.hi3d_groupnorm_fold_linear(_p(x), _p(ws), _p(gamma), _p(beta), float(eps), inst, P, C, _p(W), C, _p(bias), N,
-                                             _p(Wf), _p(biasf), _stream()), "hi3d_groupnorm_fold_linear")
+    if partials is not None and P % 64 == 0:
+        _l.check(_lib.hi3d_groupnorm_fold_linear_from_partials(_p(ws), _p(gamma), _p(beta), float(eps), inst, P, C, _p(W), C, _p(bias), N,
+                                                               _p(Wf), _p(biasf), _stream()), "hi3d_groupnorm_fold_linear_from_partials")
+    else:
+        _l.check(_lib.hi3d_groupnorm_fold_linear(_p(x), _p(ws), _p(gamma), _p(beta), float(eps), inst, P, C, _p(W), C, _p(bias), N,
+                                                 _p(Wf), _p(biasf), _stream()), "hi3d_groupnorm_fold_linear")
     if prof:
         prof.end("groupnorm_silu", 0.0, 2.0 * inst * P * C, t0)
     return Wf, biasf

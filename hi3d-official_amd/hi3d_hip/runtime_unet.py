@@ -347,7 +347,7 @@ class UNetRuntime:
             # per-frame rescaling of proj_in's weights and bias -- statistics pass + a tiny fold kernel, then the GEMM reads the
             # RAW x with frame f's weights; the normalised tensor is never written (attention.py:702-712)
             Wf, bf_ = ops.groupnorm_fold_linear(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6,
-                                                W[p + ".proj_in.w"], W[p + ".proj_in.b"], C)
+                                                W[p + ".proj_in.w"], W[p + ".proj_in.b"], C, partials=gp_in)
             h = ops.gemm(x, Wf, M=M, N=C, K=C, rowvec=bf_, rows_per_group=S, w_group_stride=C * C)
         else:
             xn = ops.groupnorm_silu(x, W[p + ".norm.g"], W[p + ".norm.b"], F_, S, C, 1e-6, silu=False, partials=gp_in)

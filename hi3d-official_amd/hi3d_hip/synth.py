@@ -77,10 +77,19 @@ def fill_module_on_device_(module: torch.nn.Module, seed: int = 1, prefix: str =
 
 
 def fill_module_(module: torch.nn.Module, seed: int = 1, prefix: str = "") -> None:
-    """Overwrite every parameter/buffer of `module` in place (keys = state_dict keys)."""
+    """Overwrite every parameter/buffer of `module` in place (keys = state_dict keys).  Every tensor has its own generator (seeded
+    by its key), so the draws are independent of each other and of the order: large modules are drawn on a thread pool (torch's
+    CPU normal sampler is serial per call and releases the GIL: the 1.5 B parameters of the full UNet took ~40 s on one thread)."""
     sd = module.state_dict()
-    new = {k: synth_tensor(prefix + k, v.shape, seed).to(v.dtype) for k, v in sd.items()
-           if v.dtype.is_floating_point}
+    keys = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    draw = lambda k: synth_tensor(prefix + k, sd[k].shape, seed).to(sd[k].dtype)
+    if sum(sd[k].numel() for k in keys) > (1 << 24):
+        import concurrent.futures as cf
+        import os
+        with cf.ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+            new = dict(zip(keys, ex.map(draw, keys)))
+    else:
+        new = {k: draw(k) for k in keys}
     module.load_state_dict(new, strict=False)
 
 

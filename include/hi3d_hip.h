@@ -499,6 +499,12 @@ int hi3d_ffn_geglu_ln(const void* x, const float* ln_gamma, const float* ln_beta
 int hi3d_groupnorm_fold_linear(const void* x, float* ws, const float* gamma, const float* beta, float eps,
                                int32_t inst, int32_t P, int32_t C, const void* W, int32_t ldw, const float* bias, int32_t N,
                                void* Wf, float* biasf, void* stream);
+/* ... with the partial sums of x already in ws, emitted by the producer of x (hi3d_gemm_desc.gn_partial; P % 64 == 0): finalize +
+ * fold only -- the norm does not read x at all (round 6; sgm/modules/attention.py:702-712 after a ResBlock whose blend epilogue
+ * emitted the sums). */
+int hi3d_groupnorm_fold_linear_from_partials(float* ws, const float* gamma, const float* beta, float eps, int32_t inst, int32_t P,
+                                             int32_t C, const void* W, int32_t ldw, const float* bias, int32_t N, void* Wf,
+                                             float* biasf, void* stream);
 
 /* out = in.permute(perm) for a 4-D array of rows: in[dims[0]][dims[1]][dims[2]][dims[3]][row_bytes] (row_bytes % 16 == 0),
  * out[dims[perm[0]]][dims[perm[1]]][dims[perm[2]]][dims[perm[3]]][row_bytes].  The pack / unpack around the frame <-> space

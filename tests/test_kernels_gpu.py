@@ -529,6 +529,21 @@ def test_groupnorm_folded_into_the_linear_layer(dev):
     assert relerr(out3, xn @ w3.T) < BF16_TOL
     with pytest.raises(ops._l.Hi3dError):               # a tile must lie inside one group
         ops.gemm(xd, Wf, M=inst * P, N=C, K=C, rowvec=bf_, rows_per_group=384, w_group_stride=C * C)
+    # round 6: the statistics from the PRODUCER of x (a GEMM that adds a residual and emits the partial sums of its output):
+    # hi3d_groupnorm_fold_linear_from_partials reads no activation at all
+    inst2, P2 = 4, 16384                                                 # (256 tiles of 256 x 320: the wide tile, which emits the sums)
+    a = bf(rnd((inst2 * P2, C), 311)).to(dev)
+    wp = bf(rnd((C, C), 312, C ** -0.5)).to(dev)
+    r1 = (bf(rnd((inst2 * P2, C), 313)) + 0.5).to(dev)
+    x2, gp = ops.gemm(a, wp, M=inst2 * P2, N=C, K=C, bias=biasd, R1=r1, gn=(inst2, P2))
+    assert gp is not None
+    Wa, ba = ops.groupnorm_fold_linear(x2, gd, bd, inst2, P2, C, 1e-6, wd, biasd, C, partials=gp)
+    Wb, bb = ops.groupnorm_fold_linear(x2, gd, bd, inst2, P2, C, 1e-6, wd, biasd, C)
+    oa = ops.gemm(x2, Wa, M=inst2 * P2, N=C, K=C, rowvec=ba, rows_per_group=P2, w_group_stride=C * C)
+    ob = ops.gemm(x2, Wb, M=inst2 * P2, N=C, K=C, rowvec=bb, rows_per_group=P2, w_group_stride=C * C)
+    xn2 = F.group_norm(x2.float().cpu().reshape(inst2, P2, C).permute(0, 2, 1), 32, g, b, 1e-6).permute(0, 2, 1).reshape(inst2 * P2, C)
+    print(f"... statistics from the producer's partial sums: vs fp32 {relerr(oa, xn2 @ w.T + bias):.2e}, vs the fold with its own statistics {relerr(oa, ob.float().cpu()):.2e}")
+    assert relerr(oa, xn2 @ w.T + bias) < BF16_TOL and relerr(oa, ob.float().cpu()) < 8e-3
 
 
 @pytest.mark.parametrize("inst,P,C1,C2,silu", [(3, 100, 64, 64, True), (2, 777, 320, 640, True), (2, 64, 1280, 1280, False),
