@@ -40,4 +40,4 @@ for inst, P, C, C1 in SHAPES:
         x = torch.randn((inst * P, C), device=dev).to(torch.bfloat16)
         us = timeit(lambda: ops.groupnorm_silu(x, g, b, inst, P, C, 1e-5))
     mb = inst * P * C * 2 / 1e6
-    print(f"  inst={inst:3d} P={P:6d} C={C:5d} {'cat2' if C1 else '    '} {mb:7.1f} MB  {us:7.1f} us  {2 * mb / us * 1e-3 * 1e3:7.0f} GB/s(alg)")
+    print(f"  inst={inst:3d} P={P:6d} C={C:5d} {'cat2' if C1 else '    '} {mb:7.1f} MB  {us:7.1f} us  {2 * mb / us * 1e3:7.0f} GB/s(alg)")

@@ -231,7 +231,12 @@ def bench_sweep():
         cells = "  ".join(f"{v}:{best[v]:7.3f}ms {fl / best[v] / 1e9:6.0f}TF" for v in vs)
         print(f"  {label:52s} {cells}", flush=True)
 
-    print("== dense")
+    # KB_HALF=1: the launches of the two-stream step -- the CFG halves of the two largest levels run as half-batch launches
+    half = os.environ.get("KB_HALF", "0") == "1"
+    if half:
+        dense = [(M // 2 if M >= 131072 else M, N, K, kind) for M, N, K, kind in dense]
+        conv = [(Fr // 2 if (Fr == 32 and H >= 64) else Fr, H, Cin, Cout, st, up, res) for Fr, H, Cin, Cout, st, up, res in conv]
+    print("== dense" + (" (half-batch launches of the two largest levels)" if half else ""))
     for M, N, K, kind in dense:
         A, W = rb(M, K), rb(N, K)
         bias = torch.randn(N, device=dev)
