@@ -125,11 +125,14 @@ typedef struct hi3d_gemm_desc {
   const void* A2;
   int32_t K1, lda2;
   /* GroupNorm statistics of the OUTPUT from the producer (round 4; NULL = off): when the launch qualifies
-   * (hi3d_gemm_gn_partial_supported: wide tile, M % 256 == 0, N a whole number of tiles, no R1 / R2 / a1 / a2, bf16 out) the
+   * (hi3d_gemm_gn_partial_supported: wide tile, M % 256 == 0, N a whole number of tiles, bf16 out; round 6: R1 / R2 / a1 / a2 are
+   * allowed -- 16-byte residual rows, one row group per 256-row tile --, the sums are then those of the FINAL values) the
    * kernel also writes, per 64-row block b of the output and per group g of N / 32 channels, the (sum, sum of squares) of the
    * fp32 results to gn_partial[b * 64 + 2 g + {0, 1}] -- M / 64 * 64 floats, the partial-sum layout of hi3d_groupnorm_silu's
    * workspace with 64-pixel blocks -- so the GroupNorm that follows (openaimodel.py:292-294 `out_layers` after the
-   * `in_layers` conv; the time_stack likewise) reads the tensor once (hi3d_groupnorm_silu_from_partials). */
+   * `in_layers` conv; the time_stack likewise; round 6: openaimodel.py:328-354 in_layers.0 after the previous block's
+   * out_layers.3 + skip / proj_out + x, video_model.py:62-81 the time_stack's in_layers.0, attention.py:702 norm) reads the
+   * tensor once (hi3d_groupnorm_silu_from_partials). */
   float* gn_partial;
   /* One weight matrix per row group (round 4; 0 = one shared W): rows [g * rows_per_group, (g + 1) * rows_per_group) multiply
    * W + g * w_group_stride elements.  The transformer's GroupNorm(eps 1e-6, no SiLU) in front of proj_in
