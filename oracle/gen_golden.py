@@ -241,6 +241,24 @@ def gen_sampler_at_size(name, cfg, T, hw, steps, n_run, max_scale, stage, wseed=
     print(f"{name}: {n_run} steps, mean {sum(step_s) / len(step_s):.1f}s/step, total {time.time() - t0:.0f}s", flush=True)
 
 
+DECODED_CROP = 512
+
+
+def compact_decoded(name):
+    """One-off for a fixture written before the crop above existed (the 4-hour v02_s2_full_25step job of round 6 was already
+    running): keep the centre crop of its fp16 image, as gen_v02_at_size now does.  Nothing is recomputed."""
+    path = os.path.join(GOLD, name + ".pt")
+    fx = torch.load(path, weights_only=False)
+    if "decoded_crop" in fx:
+        return
+    img = fx["decoded_f16"]
+    c0 = (img.shape[-1] - DECODED_CROP) // 2
+    fx.update(decoded_crop=(c0, DECODED_CROP), decoded_absmax=float(img.float().abs().max()),
+              decoded_f16=img[..., c0:c0 + DECODED_CROP, c0:c0 + DECODED_CROP].clone())
+    torch.save(fx, path)
+    print(f"{name}: decoded_f16 cropped to {tuple(fx['decoded_f16'].shape)}")
+
+
 def gen_v02_at_size(name, cfg, T, hw, steps, max_scale, keep, wseed=1, iseed=0, decode_frames=None):
     """BASELINE config 3 end to end on the reference classes: the stage-2 refine loop of pipeline_i2v_eval_v02.py:103-135 (re-noising
     blend alpha_i = (0.5 (1 + cos(i / 25)))^40 with the per-frame encoded latents, then EulerEDMSampler.step_call with CFG 1 -> 2)
@@ -297,7 +315,12 @@ def gen_v02_at_size(name, cfg, T, hw, steps, max_scale, keep, wseed=1, iseed=0, 
         del unet
         t1 = time.time()
         img, vid = _ref_decode_frames(latents, decode_frames)
-        fx.update(decode_frames=list(decode_frames), decoded_f16=img.to(torch.float16), decoded_u8=vid, ref_decode_seconds=time.time() - t1)
+        # the fp16 image is kept for a centre crop only (PSNR of the unclamped decoder output: 2 x 3 x 1024^2 fp16 would be 12.6 MB);
+        # the uint8 frames of tensor2vid are kept whole
+        c0 = (img.shape[-1] - DECODED_CROP) // 2
+        fx.update(decode_frames=list(decode_frames), decoded_crop=(c0, DECODED_CROP),
+                  decoded_f16=img[..., c0:c0 + DECODED_CROP, c0:c0 + DECODED_CROP].to(torch.float16).clone(), decoded_u8=vid,
+                  decoded_absmax=float(img.abs().max()), ref_decode_seconds=time.time() - t1)
     torch.save(fx, os.path.join(GOLD, name + ".pt"))
     try:
         os.remove(os.path.join(GOLD, name + ".partial.pt"))
@@ -546,8 +569,9 @@ def main():
         # reference decode + tensor2vid of the final latents of the two full-width 25-step fixtures (4 frames of 128 x 128)
         jobs["sampler_s1_w320_25step_img"] = lambda: gen_decode_of("sampler_s1_w320_25step_img", "sampler_s1_w320_25step")
         jobs["v02_w320_25step_img"] = lambda: gen_decode_of("v02_w320_25step_img", "v02_w320_25step")
+    jobs["compact_v02_s2_full_25step"] = lambda: compact_decoded("v02_s2_full_25step")      # (explicit: --only)
     for k, fn in jobs.items():
-        if a.only is None or a.only == k:
+        if (a.only is None and not k.startswith("compact_")) or a.only == k:
             fn()
 
 
