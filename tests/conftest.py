@@ -61,7 +61,8 @@ ROW_TESTS = [
         "test_pipeline_gpu.py::test_pack_cache_cold_and_warm_are_bit_identical"]),
     ("N1 fp8 attention (BASELINE config 5)", [
         "test_at_size_gpu.py::test_unet_full_size_stage2_matches_reference_golden[fp8",
-        "test_at_size_gpu.py::test_sampler_25_steps_full_width_fp8_attention", "test_unet_gpu.py::test_unet_fp8_attention_paths"]),
+        "test_at_size_gpu.py::test_sampler_25_steps_full_width_fp8_attention", "test_unet_gpu.py::test_unet_fp8_attention_paths",
+        "test_timed_path_gpu.py::test_stage2_headline_sampler_steps_fp8_attention_match_reference"]),
 ]
 # run last: timing-stress / race screens / long repeatability runs, and tests of code paths that are OFF by default
 LAST_TESTS = ["isa_timing_stress", "race_screen", "ragged_repeatable", "test_groupnorm_folded_into_the_linear_layer",
