@@ -38,7 +38,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   constexpr int NW = WM * 2;                 // waves per block
   constexpr bool UP2X = AMODE_ == A_CONV3X3_UP2X;
   constexpr bool DENSE2 = AMODE_ == A_DENSE2;
-  constexpr int AMODE = UP2X ? HI3D_A_CONV3X3 : DENSE2 ? HI3D_A_DENSE : AMODE_;
+  constexpr bool PHASE = AMODE_ == A_CONV3X3_PHASE;      // (wide tiles only: the per-wave store loop below places the rows)
+  constexpr int AMODE = (UP2X || PHASE) ? HI3D_A_CONV3X3 : DENSE2 ? HI3D_A_DENSE : AMODE_;
   constexpr int BM = WM * 64, BN = 32 * NT;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // Conv3d (3,1,1), clip boundaries: when the block's rows lie in one frame (HW % BM == 0) and that frame is the first / last
   // of its clip, tap 0 / tap 2 reads nothing but the clip's zero padding -- its K steps are left out (2 of 3 T taps of such a
   // block: 4 % of the launch at T = 16).  Block-uniform: scalar registers only.
-  int tap_lo = 0, tap_hi = AMODE_ == HI3D_A_CONV3X3 || AMODE_ == A_CONV3X3_UP2X ? p.ntap : 3;
+  int tap_lo = 0, tap_hi = AMODE_ == HI3D_A_CONV3X3 || AMODE_ == A_CONV3X3_UP2X || AMODE_ == A_CONV3X3_PHASE ? p.ntap : 3;
   int nk_ = p.ksplit > 1 ? p.nk_split : p.K / BK;
   if (AMODE_ == HI3D_A_CONVT3 && p.tskip && p.ksplit <= 1 && p.HW % BM == 0 && p.T > 1) {
     const int t = (m0 / p.HW) % p.T;
@@ -89,6 +90,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     nk_ = (tap_hi - tap_lo) * (p.Cin / BK);
   }
   const int nk = nk_;
+  // A_CONV3X3_PHASE: the 16 rows of store pass mt of this wave are 16 consecutive pixels of ONE low-resolution image row (16 | Win):
+  // they land on every second row of the 2x image from a per-pass base row -- twice the row pitch, the base as the store's scalar
+  // offset.  The four bases are computed HERE, before the K loop (an integer division each, wave-uniform), not in the store loop.
+  int so_ph[4] = {0, 0, 0, 0};
+  if constexpr (PHASE) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r0 = __builtin_amdgcn_readfirstlane(m0 + wm * 64 + mt * 16);
+      so_ph[mt] = __builtin_amdgcn_readfirstlane((2 * r0 + 2 * p.Win * (r0 / p.Win) + p.phase_c) * p.ldo * 2);
+    }
+  }
 
 
   // ---- per-thread gather state.  LDS row r of a tile is filled by the 8 lanes
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
     };
     if (EPI == HI3D_EPI_AFFINE && p.gn_part && !p.gn_post) emit_gn_stats();
     const __amdgpu_buffer_rsrc_t rsOw =
-        __builtin_amdgcn_make_buffer_rsrc((char*)p.out + ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0) * osz, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (PHASE ? (long)wcol0 : ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0)) * osz, 0, 0x7fffffff, 0x00020000);
     // chunk i of a pass = lane + 64 i: slab row / column, the same in all four passes -- its LDS, bias, output and
     // residual offsets are computed once per tile (the store loop was VALU-bound on this index arithmetic: ~80
     // instructions per chunk, 20 chunks per wave; the accumulators leave ~30 registers for it)
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       w_col[i] = (c - w_row[i] * WCPR) * 8;
       const bool in = c < 16 * WCPR && wcol0 + w_col[i] < N_out;
       w_lds[i] = in ? w_row[i] * WROW + w_col[i] * 4 : 0;      // (void chunks read slab bytes 0..31 and store nothing)
-      w_out[i] = in ? (unsigned)((w_row[i] * p.ldo + w_col[i]) * osz) : INV;
+      w_out[i] = in ? (unsigned)((w_row[i] * (PHASE ? 2 * p.ldo : p.ldo) + w_col[i]) * osz) : INV;
       w_r1[i] = in ? (unsigned)((w_row[i] * p.ldr1 + w_col[i]) * 2) : INV;
       w_r2[i] = in ? (unsigned)((w_row[i] * p.ldr2 + w_col[i]) * 2) : INV;
     }
@@ -713,7 +725,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       // interior wave tiles of the usual call (bf16 out, 16-byte rows, one group per tile, no ragged chunk): no
       // per-lane predicate and no per-chunk mode branch -- ~25 VALU instructions per chunk instead of ~80
       if (wfast) {
-        const int so = mt * 16 * p.ldo * osz;
+        const int so = PHASE ? so_ph[mt] : mt * 16 * p.ldo * osz;
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
           const f32x4 lo = *(const f32x4*)(slab + w_lds[i]), hi = *(const f32x4*)(slab + w_lds[i] + 16);
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           }
         }
         const unsigned vo = (ok && !(p.abl & 1)) ? w_out[i] : INV;
-        const int so = mt * 16 * p.ldo * osz;
+        const int so = PHASE ? so_ph[mt] : mt * 16 * p.ldo * osz;
         if (p.out_fp32) {
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsOw, vo, so, 0);
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsOw, has8 ? vo + 16 : INV, so, 0);
@@ -932,6 +944,9 @@ int dispatch(const GemmParams& p, int amode, int epi, hipStream_t s) {
         HI3D_FAIL(HI3D_EINVAL, "gemm: two-source A has no instantiation for this tile");
     case HI3D_A_CONV3X3: return p.up2x ? launch<WM, NT, NS, A_CONV3X3_UP2X, HI3D_EPI_AFFINE, PP>(p, s)
                                         : launch<WM, NT, NS, HI3D_A_CONV3X3, HI3D_EPI_AFFINE, PP>(p, s);
+    case A_CONV3X3_PHASE:
+      if constexpr (NT > 5 && WM == 4 && PP && NS == 2) return launch<WM, NT, NS, A_CONV3X3_PHASE, HI3D_EPI_AFFINE, PP>(p, s);
+      else HI3D_FAIL(HI3D_EINVAL, "gemm: phase-placed output has no instantiation for this tile");
     case HI3D_A_CONVT3: return launch<WM, NT, NS, HI3D_A_CONVT3, HI3D_EPI_AFFINE, PP>(p, s);
   }
   HI3D_FAIL(HI3D_EINVAL, "gemm: bad amode");
@@ -1216,7 +1231,20 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (env.has_gn) p.gn = env.gn;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int amode = two ? A_DENSE2 : d->amode;
+  int amode = two ? A_DENSE2 : d->amode;
+  p.phase_c = 0;
+  if (d->conv_phase) {
+    const int ph = d->conv_phase - 1;
+    if (ph < 0 || ph > 3) HI3D_FAIL(HI3D_EINVAL, "conv3x3: conv_phase must be 0 or 1..4");
+    const bool ok = d->amode == HI3D_A_CONV3X3 && d->conv_ntap > 0 && !d->up2x && d->stride == 1 && d->Hout == d->Hin &&
+                    d->Wout == d->Win && d->Win % 16 == 0 && d->M % 256 == 0 && d->N % tile == 0 && (variant == 7 || variant == 8) &&
+                    ksplit == 1 && !d->R1 && !d->R2 && !d->rowvec && !d->a1 && !d->a2 && !d->out_fp32 && p.vec8 && !d->gn_partial &&
+                    4L * d->M * d->ldo * 2 < (1L << 31);
+    if (!ok) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: phase-placed output needs a tap subset, a wide tile (full tiles, >= 256 of them), Win % 16 == 0, "
+                                     "a bias-only bf16 epilogue and a 2x image below 2 GiB");
+    p.phase_c = (ph >> 1) * 2 * d->Win + (ph & 1);
+    amode = A_CONV3X3_PHASE;
+  }
   p.ksplit = 1; p.nk_split = d->K / BK;
   if (ksplit > 1) {
     int dev = -1;

@@ -39,10 +39,15 @@ struct GemmParams {
   // Conv3d (3,1,1): a block whose rows lie in ONE frame at either end of its clip skips the K steps of the tap that reads the
   // clip's zero padding (round 6; 0 = walk all three taps, HI3D_CONVT_SKIP=0)
   int tskip;
+  // A_CONV3X3_PHASE: the phase constant c = a * 2 Win + b of the up-sampled image this tap-subset launch writes into (see below)
+  int phase_c;
 };
 
 constexpr int BK = 64;
 constexpr int A_CONV3X3_UP2X = 3;   // internal: HI3D_A_CONV3X3 with up2x (own instantiation: the plain gather stays lean)
+constexpr int A_CONV3X3_PHASE = 5;  // internal: HI3D_A_CONV3X3 (tap subset) whose output rows go to phase (a, b) of a 2x up-sampled image: row
+                                    // p = (f Hin + i) Win + j is stored as row 2 p + 2 Win (p / Win) + c of `out`, c = a * 2 Win + b
+                                    // (hi3d_gemm_desc.conv_phase; wide ping-pong tiles only: the per-wave store loop places the rows)
 constexpr int A_DENSE2 = 4;         // internal: HI3D_A_DENSE with two K segments from two tensors (GemmParams.A2)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

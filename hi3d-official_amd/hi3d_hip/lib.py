@@ -24,7 +24,7 @@ EXPORTS = [
     "hi3d_resize_bilinear_nhwc", "hi3d_dpt_head_out", "hi3d_depth_normalize_unshuffle", "hi3d_resample_axis", "hi3d_permute_rows",
 ]
 
-ABI_VERSION = 2          # == HI3D_ABI_VERSION of the include/hi3d_hip.h this binding was written against (GemmDesc below is that layout)
+ABI_VERSION = 3          # == HI3D_ABI_VERSION of the include/hi3d_hip.h this binding was written against (GemmDesc below is that layout)
 A_DENSE, A_CONV3X3, A_CONVT3 = 0, 1, 2
 EPI_AFFINE, EPI_GEGLU = 0, 1
 
@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("Wout", C.c_int32), ("stride", C.c_int32), ("up2x", C.c_int32),
         ("T", C.c_int32), ("HW", C.c_int32), ("tile_n", C.c_int32), ("pad_br_only", C.c_int32),
         ("A2", C.c_void_p), ("K1", C.c_int32), ("lda2", C.c_int32), ("gn_partial", C.c_void_p), ("w_group_stride", C.c_int64),
-        ("conv_ntap", C.c_int32), ("conv_taps", C.c_uint32),
+        ("conv_ntap", C.c_int32), ("conv_taps", C.c_uint32), ("conv_phase", C.c_int32),
     ]
 
 

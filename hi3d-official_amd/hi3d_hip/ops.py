@@ -110,6 +110,8 @@ def gemm_desc(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_p
         if taps:
             d.conv_ntap = len(taps)
             d.conv_taps = sum(int(t) << (4 * k) for k, t in enumerate(taps))
+        if conv3x3.get("phase") is not None:         # (a, b): rows go to pixel (2 i + a, 2 j + b) of `out`, the full 2x image
+            d.conv_phase = 1 + 2 * int(conv3x3["phase"][0]) + int(conv3x3["phase"][1])
     elif convt3 is not None:
         d.amode = _l.A_CONVT3
         d.T, d.HW, d.Cin = int(convt3["T"]), int(convt3["HW"]), int(convt3["Cin"])
@@ -444,17 +446,38 @@ def groupnorm_fold_linear(x, gamma, beta, inst, P, C, eps, W, bias, N, partials=
     return Wf, biasf
 
 
-def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C):
+# HI3D_UP_PHASE_PLACED=0: planar phase images + hi3d_permute_rows (rounds 4-5).  Default (round 6): the four phase convolutions of an
+# up-sampling conv store their rows straight into the 2x image (hi3d_gemm_desc.conv_phase) -- round 4's parked experiment, rebuilt
+# with the per-pass base rows computed BEFORE the K loop (the parked form divided inside the store loop and left a few rows of
+# store pass 0 unwritten); bit-identical to the planar form at every UNet / VAE shape, 50 repetitions (tests/test_kernels_gpu.py)
+UP_PHASE_PLACED = os.environ.get("HI3D_UP_PHASE_PLACED", "1") != "0"
+_PHASE_PLACED_OK = {}
+
+
+def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C, placed=None):
     """Upsample(nearest 2x) + conv3x3 pad 1 on x [frames * H * Wd, C] (channels-last rows) -> [frames * 2H * 2Wd, C] as four 2x2
     phase convolutions on the low-resolution image (pack.pack_conv3x3_up_phases: w_phases[a * 2 + b] = [C, 4 * C]): the phases are
-    written planar [a][b][(f i)][j] and interleaved to [(f i)][a][j][b] by hi3d_permute_rows.  (Storing the phases in place from
-    the GEMM epilogue was built and is parked with an open bug: tools/probes/phase_placed_store_experiment.diff.txt.)"""
+    written planar [a][b][(f i)][j] and interleaved to [(f i)][a][j][b] by hi3d_permute_rows -- or, `placed` (default:
+    HI3D_UP_PHASE_PLACED) and where the launch qualifies (wide tile, Wd % 16 == 0), every phase stores its rows straight into the 2x
+    image (hi3d_gemm_desc.conv_phase)."""
     Ml = frames * H * Wd
+    placed = UP_PHASE_PLACED if placed is None else placed
+    geo = lambda ph: dict(Hin=H, Win=Wd, Cin=C, Hout=H, Wout=Wd, stride=1, up2x=0,
+                          taps=tuple(((ph >> 1) + dy) * 3 + ((ph & 1) + dx) for dy in (0, 1) for dx in (0, 1)))
+    key = (x.device.index, Ml, H, Wd, C)
+    if placed and _PHASE_PLACED_OK.get(key, True):
+        out = torch.empty((4 * Ml, C), device=x.device, dtype=torch.bfloat16)
+        try:
+            for ph in range(4):
+                gemm(x, w_phases[ph], M=Ml, N=C, K=4 * C, bias=bias, out=out, conv3x3=dict(geo(ph), phase=(ph >> 1, ph & 1)))
+            return out
+        except _l.Hi3dError:
+            if ph != 0:                              # (the shape check is the same for the four phases: it fails at the first or never)
+                raise
+            _PHASE_PLACED_OK[key] = False
     tmp = torch.empty((4, Ml, C), device=x.device, dtype=torch.bfloat16)
     for ph in range(4):
-        taps = tuple(((ph >> 1) + dy) * 3 + ((ph & 1) + dx) for dy in (0, 1) for dx in (0, 1))
-        gemm(x, w_phases[ph], M=Ml, N=C, K=4 * C, bias=bias, out=tmp[ph],
-             conv3x3=dict(Hin=H, Win=Wd, Cin=C, Hout=H, Wout=Wd, stride=1, up2x=0, taps=taps))
+        gemm(x, w_phases[ph], M=Ml, N=C, K=4 * C, bias=bias, out=tmp[ph], conv3x3=geo(ph))
     return permute_rows(tmp, (2, 2, frames * H, Wd), (2, 0, 3, 1)).reshape(4 * Ml, C)
 
 

@@ -51,8 +51,9 @@ extern "C" {
  * hi3d_gemm_desc, whose missing tail the library would read as garbage A2 / gn_partial / conv_taps.
  *   1: rounds 1-4 (the descriptor GREW inside version 1 in round 4 -- A2, K1, lda2, gn_partial, w_group_stride, conv_ntap,
  *      conv_taps -- which is the mistake this comment exists to prevent);
- *   2: round 5 -- that descriptor, hi3d_time_mix_small_k3.                                                                 */
-#define HI3D_ABI_VERSION 2
+ *   2: round 5 -- that descriptor, hi3d_time_mix_small_k3;
+ *   3: round 6 -- hi3d_gemm_desc.conv_phase appended.                                                                      */
+#define HI3D_ABI_VERSION 3
 int hi3d_abi_version(void);
 /* static description of the last error on this host thread (never NULL) */
 const char* hi3d_last_error(void);
@@ -146,6 +147,12 @@ typedef struct hi3d_gemm_desc {
    * weights are sums of the 3x3 weights: 4/9 of the multiply-adds (hi3d_hip/pack.py:pack_conv3x3_up_phases). stride 1, no up2x. */
   int32_t conv_ntap;
   uint32_t conv_taps;
+  /* conv_phase = 1 + 2 a + b (0 = off; round 6, ABI 3): the launch is phase (a, b) of such an up-sampling conv and `out` is the FULL 2x
+   * image [frames * 2 Hin * 2 Win, ldo]: row (f, i, j) of this launch is stored as pixel (f, 2 i + a, 2 j + b) -- no planar phase
+   * images, no interleave pass (openaimodel.py:107-146 Upsample; model.py:67-71).  Needs a tap subset, the wide tiles (full tiles,
+   * >= 256 of them), Win % 16 == 0, a bias-only bf16 epilogue, the 2x image below 2 GiB; HI3D_ESHAPE otherwise (the caller
+   * falls back to planar phase images + hi3d_permute_rows). */
+  int32_t conv_phase;
 } hi3d_gemm_desc;
 
 int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream);

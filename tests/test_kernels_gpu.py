@@ -333,6 +333,38 @@ def test_upsample_conv_as_four_phase_convs(dev, Fr, H, W_, C):
                  conv3x3=dict(Hin=H, Win=W_, Cin=C, Hout=2 * H, Wout=2 * W_, stride=1, up2x=1, taps=(0, 1, 3, 4)))
 
 
+@pytest.mark.parametrize("Fr,H,W_,C", [(4, 128, 128, 320), (16, 64, 64, 640), (32, 32, 32, 1280), (1, 256, 256, 512), (1, 512, 512, 256),
+                                        (22, 64, 48, 320)])
+def test_upsample_phase_convs_placed_in_the_2x_image(dev, Fr, H, W_, C):
+    """hi3d_gemm_desc.conv_phase (round 4's parked experiment, rebuilt in round 6): the four phase convolutions of an up-sampling
+    conv store their rows straight into the 2x image -- twice the row pitch, a per-pass base row computed before the K loop --
+    instead of planar phase images + hi3d_permute_rows.  Bit-identical to the planar + interleave form at the UNet's and the VAE
+    decoder's shapes (both wide tiles), repeatedly, into NaN-filled output (an unwritten row shows); launches that do not qualify
+    say so and the wrapper falls back."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3_up_phases
+    g = torch.Generator(device=dev).manual_seed(410 + H)
+    xt = torch.randn((Fr * H * W_, C), device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn((C, C, 3, 3), generator=torch.Generator().manual_seed(411)) * (9 * C) ** -0.5).to(torch.bfloat16).float()
+    b = torch.randn((C,), generator=torch.Generator().manual_seed(412)).to(dev)
+    wp = [p_.to(dev) for p_, _ in pack_conv3x3_up_phases(w)]
+    planar = ops.upsample_conv_phases(xt, wp, b, Fr, H, W_, C, placed=False)
+    Ml = Fr * H * W_
+    for rep in range(50 if (Fr, H, C) == (4, 128, 320) else 5):   # (the parked round-4 form failed in ~1 of 800 wave tiles of this very shape)
+        out = torch.full((4 * Ml, C), float("nan"), device=dev, dtype=torch.bfloat16)
+        for ph in range(4):
+            taps = tuple(((ph >> 1) + dy) * 3 + ((ph & 1) + dx) for dy in (0, 1) for dx in (0, 1))
+            ops.gemm(xt, wp[ph], M=Ml, N=C, K=4 * C, bias=b, out=out,
+                     conv3x3=dict(Hin=H, Win=W_, Cin=C, Hout=H, Wout=W_, stride=1, up2x=0, taps=taps, phase=(ph >> 1, ph & 1)))
+        bad = (out != planar).any(dim=1)
+        assert not bool(bad.any()), f"rep {rep}: {int(bad.sum())} of {4 * Ml} rows differ from the planar + interleave form " \
+                                    f"(first: {bad.nonzero()[:8].flatten().tolist()}, NaN rows: {int(torch.isnan(out.float()).any(dim=1).sum())})"
+    assert torch.equal(ops.upsample_conv_phases(xt, wp, b, Fr, H, W_, C, placed=True), planar)
+    with pytest.raises(ops._l.Hi3dError):               # Win % 16 != 0: not a placed launch (the wrapper falls back to planar)
+        ops.gemm(xt[:Fr * H * 24], wp[0], M=Fr * H * 24, N=C, K=4 * C, bias=b, out=torch.empty((4 * Fr * H * 24, C), device=dev, dtype=torch.bfloat16),
+                 conv3x3=dict(Hin=H, Win=24, Cin=C, Hout=H, Wout=24, stride=1, up2x=0, taps=(0, 1, 3, 4), phase=(0, 0)))
+
+
 @pytest.mark.parametrize("Fr,H,W_,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 16, 12, 128, 128, 2, 0),
                                                          (2, 8, 8, 64, 160, 1, 1), (1, 5, 7, 192, 64, 1, 0),
                                                          (2, 9, 9, 64, 64, 2, 0)])
