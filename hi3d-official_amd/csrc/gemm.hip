@@ -1191,6 +1191,11 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     variant = 7;
   } else if (d->N % 256 == 0 && wide_fits(256)) {
     variant = 8;
+  } else if (d->amode == HI3D_A_CONV3X3 && d->N == 128 && d->tile_n == 0 && d->stride == 1 && !d->up2x && d->M >= 768 * 128) {
+    // round 6: the VAE's 128-channel convs at 512^2 / 1024^2 (one n-tile, thousands of m-tiles, K = 1152 / 2304): a third
+    // resident block hides more of a tile's start-up and store phase than the second ring stage did -- 0.450 -> 0.393 ms with
+    // the skip, 0.396 -> 0.341 without, 256 -> 128: 0.654 -> 0.620 (profiles/r06s_vae_variant_sweep.log; bit-identical)
+    variant = 3;
   }
   if (env.has_variant) variant = env.variant;
   if (two && variant != 7) variant = 0;           // two-source A: built for the 128-row 2-stage tile and the 256 x 320 ping-pong tile

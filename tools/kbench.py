@@ -105,7 +105,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1", "tattn")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1", "tattn", "vaesweep")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -314,3 +314,44 @@ def bench_temporal_ab():
 
 if len(sys.argv) > 1 and sys.argv[1] == "tattn":
     bench_temporal_ab()
+
+
+def bench_vae_sweep():
+    """kbench.py vaesweep [variants...] : the VAE decoder's conv shapes (one frame) under each tile variant (HI3D_GEMM_VARIANT,
+    re-read through hi3d_gemm_reload_env); 'h' = the host heuristic."""
+    variants = sys.argv[2:] or ["h", "0", "1", "2", "3", "6", "8"]
+    shapes = ((1, 1024, 128, 128, True), (1, 1024, 128, 128, False), (1, 1024, 256, 128, False), (1, 512, 256, 256, True),
+              (1, 512, 512, 256, False), (1, 256, 512, 512, True), (4, 1024, 128, 128, True))
+    for Fr, H, Cin, Cout, res in shapes:
+        M, K = Fr * H * H, 9 * Cin
+        A, W = rb(M, Cin), rb(Cout, K)
+        bias = torch.randn(Cout, device=dev)
+        R1 = rb(M, Cout) if res else None
+        out = torch.empty((M, Cout), device=dev, dtype=torch.bfloat16)
+        geo = dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up2x=0)
+        ref = None
+        line = f"conv F={Fr} H={H} {Cin}->{Cout}{' +R1' if res else ''}:"
+        for v in variants:
+            if v == "h":
+                os.environ.pop("HI3D_GEMM_VARIANT", None)
+            else:
+                os.environ["HI3D_GEMM_VARIANT"] = v
+            ops.gemm_reload_env()
+            try:
+                ms = timeit(lambda: ops.gemm(A, W, M=M, N=Cout, K=K, bias=bias, R1=R1, conv3x3=geo, out=out), iters=5, warm=2)
+            except Exception as e:      # (a variant the shape does not admit)
+                line += f"  {v}: n/a ({str(e)[:30]})"
+                continue
+            same = ""
+            if ref is None:
+                ref = out.clone()
+            else:
+                same = "" if torch.equal(ref, out) else " (differs)"
+            line += f"  {v}: {ms:.3f} ms {2.0 * M * Cout * K / ms / 1e9:.0f} TF{same}"
+        print(line, flush=True)
+    os.environ.pop("HI3D_GEMM_VARIANT", None)
+    ops.gemm_reload_env()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "vaesweep":
+    bench_vae_sweep()
