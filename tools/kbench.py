@@ -236,7 +236,12 @@ def bench_sweep():
     if half:
         dense = [(M // 2 if M >= 131072 else M, N, K, kind) for M, N, K, kind in dense]
         conv = [(Fr // 2 if (Fr == 32 and H >= 64) else Fr, H, Cin, Cout, st, up, res) for Fr, H, Cin, Cout, st, up, res in conv]
-    print("== dense" + (" (half-batch launches of the two largest levels)" if half else ""))
+    # KB_DIV=8: the launches of ONE RANK of a clip-parallel job (cfg 2 x sp 4: an eighth of every M; VAE rows dropped)
+    div = int(os.environ.get("KB_DIV", "1"))
+    if div > 1:
+        dense = [(M // div, N, K, kind) for M, N, K, kind in dense if M % (div * 128) == 0 and N != 128 and N != 16384]
+        conv = [(Fr // div, H, Cin, Cout, st, up, res) for Fr, H, Cin, Cout, st, up, res in conv if Fr == 32]
+    print("== dense" + (" (half-batch launches of the two largest levels)" if half else "") + (f" (M / {div})" if div > 1 else ""))
     for M, N, K, kind in dense:
         A, W = rb(M, K), rb(N, K)
         bias = torch.randn(N, device=dev)
@@ -261,12 +266,13 @@ def bench_sweep():
         del A, W, out, R1
     print("== conv temporal")
     for H, C in convt:
-        M, K = 32 * H * H, 3 * C
+        M, K = 32 * H * H // div, 3 * C
+        HWc = H * H if div == 1 else H * H * 2 // div       # (a rank holds all 16 frames of 2 / div of the pixels of one CFG half)
         A, W, R2 = rb(M, C), rb(C, K), rb(M, C)
         bias = torch.randn(C, device=dev)
         out = torch.empty((M, C), device=dev, dtype=torch.bfloat16)
-        run(f"convt H={H} C={C} +R2", 2.0 * M * C * K,
-            lambda: ops.gemm(A, W, M=M, N=C, K=K, bias=bias, R2=R2, convt3=dict(T=16, HW=H * H, Cin=C), out=out), variants)
+        run(f"convt H={H} C={C} HW={HWc} +R2", 2.0 * M * C * K,
+            lambda: ops.gemm(A, W, M=M, N=C, K=K, bias=bias, R2=R2, convt3=dict(T=16, HW=HWc, Cin=C), out=out), variants)
         del A, W, out, R2
 
 
