@@ -89,10 +89,13 @@ def _collect_resources(out, table):
     return "\n".join(rest)
 
 
-def _spill_tolerated(mangled):
+def _spill_tolerated(mangled, scratch=0):
     """No instantiation may spill (round 2: the 256 x 320 affine / conv forms, tolerated until then, are dispatched now
-    and fit since the bias fold left the K loop)."""
-    return False
+    and fit since the bias fold left the K loop) -- with ONE measured exception (round 6): the single-stage 128 x 128 tile is
+    bounded to 128 registers so that FOUR blocks share a CU; its conv forms park a few dwords per lane OUTSIDE the K loop (one
+    store before it, one reload in the epilogue: hi3d_hip/_isa/gemm.hip.s) and are 5-11 % faster than their spill-free
+    134-register / 3-block build on the VAE's 128-channel convs (profiles/r06w_vae_variant3_4blocks.log).  Bounded at 32 B."""
+    return "gemm_bf16_kernelILi2ELi4ELi1E" in mangled and scratch <= 32
 
 
 def build(force=False, verbose=True):
@@ -120,7 +123,7 @@ def build(force=False, verbose=True):
             print(rest, file=sys.stderr)
     with open(RESOURCES, "w") as fh:
         json.dump(resources, fh, indent=0, sort_keys=True)
-    spilled = sorted(k for k, v in resources.items() if v.get("scratch", 0) and not _spill_tolerated(k))
+    spilled = sorted(k for k, v in resources.items() if v.get("scratch", 0) and not _spill_tolerated(k, v.get("scratch", 0)))
     if spilled:
         # a kernel edit that pushes a hot instantiation into scratch costs 2-3x (measured: the conv gathers
         # went 44 -> 133 ms/step with 32 B/lane of scratch) and is invisible in tests -- fail the build instead

@@ -32,8 +32,13 @@ namespace {
 //        flight across the raw s_barrier) -- hides HBM latency for the short-K shapes.
 // PP   : "ping-pong" K loop (8-wave tiles only, see below): the two waves of a SIMD run half a phase apart, one in
 //        its MFMA segment while the other reads fragments / issues LDS-DMA.
+// per-wave epilogue (every wave stages its own 64 x 16*NT tile through a private LDS slab): the wide ping-pong tiles, and -- round 6 --
+// the single-stage 128 x 128 tile (three blocks per CU: the VAE's 128-channel convs, whose 18 K steps are no longer than the
+// block-wide epilogue's barriers)
+constexpr bool WEPI_OF(int WM, int NT, int NS) { return (NT > 5 && WM == 4) || (NT == 4 && WM == 2 && NS == 1); }
+
 template <int WM, int NT, int NS, int AMODE_, int EPI, bool PP = false>
-__global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * 128, (NT == 4 && WM == 2 && NS == 1) ? 4 : 2) void gemm_bf16_kernel(const GemmParams p) {
 #if __HIP_DEVICE_COMPILE__   // buffer-resource builtins exist only in the device pass; the host pass needs just the stub
   constexpr int NW = WM * 2;                 // waves per block
   constexpr bool UP2X = AMODE_ == A_CONV3X3_UP2X;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   };
   // The wide tile (NT > 5) has 160 accumulator registers and none to park residual slabs in during the K loop:
   // it requests them one store pass ahead in the epilogue (below).
-  constexpr bool RES_EARLY = NT <= 5;
+  constexpr bool RES_EARLY = NT <= 5 && !WEPI_OF(WM, NT, NS);
 
   const int pf_kt = nk >= 2 ? nk - 2 : 0;
   int st = 0;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
   // the LDS unit keeps a wave's writes and reads in order -- and issues its residual loads / stores row-contiguous,
   // 16 bytes per lane.  The block-wide form below cost 16 k cycles per tile before any store traffic (ablation:
   // profiles/r02c_gemm_epilogue_ablation.log), as much as 6 K steps: 8 barriers, each waiting for the slowest wave.
-  constexpr bool WEPI = NT > 5 && WM == 4;
+  constexpr bool WEPI = WEPI_OF(WM, NT, NS);
   if constexpr (WEPI) {
     constexpr int WOUT = (EPI == HI3D_EPI_GEGLU) ? 8 * NT : 16 * NT;   // output columns of a wave tile
     constexpr int WROW = WOUT * 4 + 16;                                  // slab row pitch (bytes)
@@ -602,6 +607,18 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
       else if (cpg * 2 == LC) gn_block(std::integral_constant<int, 2>{});
       else gn_block(std::integral_constant<int, 1>{});
     };
+    // tiles whose accumulators do not start from bias + row vector (the single-stage 128 x 128 tile): a launch that takes
+    // statistics adds them HERE, in the accumulator layout, and its store loop skips them -- the same fp32 additions in the same order
+    const bool bias_done = !BIAS_INIT && EPI == HI3D_EPI_AFFINE && p.gn_part != nullptr;
+    if (bias_done) {
+      __syncthreads();                             // (the fold of bias + row vector into vec_lds happened inside the K loop)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 b = *(const f32x4*)(vec_lds + (wn * 16 * NT + fg * 4 * NT + nt * 4) * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][nt][0] += b[0]; acc[mt][nt][1] += b[1]; acc[mt][nt][2] += b[2]; acc[mt][nt][3] += b[3]; }
+      }
+    }
     if (EPI == HI3D_EPI_AFFINE && p.gn_part && !p.gn_post) emit_gn_stats();
     const __amdgpu_buffer_rsrc_t rsOw =
         __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (PHASE ? (long)wcol0 : ((long)ks * p.M * p.ldo + wrow0 * p.ldo + wcol0)) * osz, 0, 0x7fffffff, 0x00020000);
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
           const f32x4 lo = *(const f32x4*)(slab + w_lds[i]), hi = *(const f32x4*)(slab + w_lds[i] + 16);
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           if (EPI == HI3D_EPI_AFFINE) {
-            if (!BIAS_INIT) {
+            if (!BIAS_INIT && !bias_done) {
               const char* bp = vec_lds + (wn * WOUT + w_col[i]) * 4;
               const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 16);
 #pragma unroll
@@ -768,7 +785,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_bf16_kernel(const GemmParams
         if (w_out[i] != INV) { lo = *(const f32x4*)(slab + w_lds[i]); hi = *(const f32x4*)(slab + w_lds[i] + 16); }
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (EPI == HI3D_EPI_AFFINE) {
-          if (!BIAS_INIT) {
+          if (!BIAS_INIT && !bias_done) {
             const char* bp = vec_lds + (wn * WOUT + col) * 4;
             const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 16);
 #pragma unroll
@@ -1167,7 +1184,8 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // Hi3D shape once the loaders went to buffer addressing); 1 = 128 rows, 3 stages;
   // 2 = 256 rows, 8 waves, 3-stage ring with counted vmcnt, 1 block/CU;
   // 5 = 256 x 320 tile, 8 waves of 64 x 160 (half the L2->LDS bytes per FLOP), 1 block/CU.
-  // 3 = 128 rows, single stage, 3 blocks/CU.  Measured per shape (tools/kbench.py, MI355X):
+  // 3 = 128 rows, single stage, 3 blocks/CU (round 6: the 128-column form is held to 128 registers -- FOUR blocks/CU -- and runs
+  // the wide tiles' per-wave epilogue, statistics included).  Measured per shape (tools/kbench.py, MI355X):
   // the GEGLU GEMMs (erf epilogue, VALU heavy) gain 9-15 % from the third resident block while
   // K is short, and 12-16 % from the 256 x 320 tile (variant 5) at K >= 640; plain GEMMs gain
   // 3-7 % from the 256-row tile when both K and N are long; everything else, and every conv,
@@ -1189,13 +1207,16 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     else if (d->K >= 2560 || (d->K >= 1280 && d->N >= 2560)) variant = 2;
   } else if (wide_fits(320)) {
     variant = 7;
-  } else if (d->N % 256 == 0 && wide_fits(256)) {
-    variant = 8;
-  } else if (d->amode == HI3D_A_CONV3X3 && d->N == 128 && d->tile_n == 0 && d->stride == 1 && !d->up2x && d->M >= 768 * 128) {
-    // round 6: the VAE's 128-channel convs at 512^2 / 1024^2 (one n-tile, thousands of m-tiles, K = 1152 / 2304): a third
-    // resident block hides more of a tile's start-up and store phase than the second ring stage did -- 0.450 -> 0.393 ms with
-    // the skip, 0.396 -> 0.341 without, 256 -> 128: 0.654 -> 0.620 (profiles/r06s_vae_variant_sweep.log; bit-identical)
+  } else if (d->amode == HI3D_A_CONV3X3 && d->N % 128 == 0 && d->N <= 512 && d->tile_n == 0 && d->stride == 1 && !d->up2x &&
+             d->conv_ntap == 0 && ((long)d->M / 128) * (d->N / 128) >= 1024) {
+    // round 6: the VAE's 128- / 256- / 512-channel convs at >= 1024 tiles of 128 x 128 (K = 1152 ... 4608) on the single-stage
+    // tile, FOUR blocks per CU (128 registers, per-wave epilogue): 16 waves per CU hide a tile's start-up and store phase better
+    // than the second ring stage or the 256 x 256 ping-pong tile did -- 128 -> 128 at 1024^2: 0.484 -> 0.377 ms with the skip,
+    // 0.441 -> 0.330 without; 256 -> 256 at 512^2: 0.315 (256 x 256 tile) -> 0.290; 512 -> 512 at 256^2: 0.279 -> 0.267; the
+    // 128^2 level (512 tiles) stays on the two-stage tile (0.080 vs 0.092)  (profiles/r06w_vae_variant_sweep_4blocks.log)
     variant = 3;
+  } else if (d->N % 256 == 0 && wide_fits(256)) {
+    variant = 8;                                  // (the up-sampling convs' phase launches: the placed store needs the wide tile)
   }
   if (env.has_variant) variant = env.variant;
   if (two && variant != 7) variant = 0;           // two-source A: built for the 128-row 2-stage tile and the 256 x 320 ping-pong tile
@@ -1271,14 +1292,16 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
   // tiles only, nothing added after the accumulators (no residual / blend; a row vector only when it is per tile), and a
   // channel count whose groups are whole inside a lane's 4*NT columns
   p.gn_post = 0;
-  if (d->gn_partial && (variant == 7 || variant == 8) && d->epi == HI3D_EPI_AFFINE &&
-      !d->out_fp32 && d->M % 256 == 0 && d->N % tile == 0 && d->N % 32 == 0 && (!d->rowvec || d->rows_per_group % 256 == 0) &&
+  // (round 6: also the single-stage 128 x 128 tile, which runs the same per-wave epilogue -- the VAE's 128-channel level)
+  const bool wepi = variant == 7 || variant == 8 || (variant == 3 && tile == 128);
+  if (d->gn_partial && wepi && ksplit == 1 && d->epi == HI3D_EPI_AFFINE &&
+      !d->out_fp32 && d->M % bm == 0 && d->N % tile == 0 && d->N % 32 == 0 && (!d->rowvec || d->rows_per_group % bm == 0) &&
       ((uintptr_t)d->gn_partial & 7) == 0 && !env.gn_fused_off) {
-    const int lc = tile == 320 ? 40 : 32, cpg = d->N / 32;
+    const int lc = tile == 320 ? 40 : tile == 256 ? 32 : 16, cpg = d->N / 32;
     const bool whole = cpg == lc || cpg * 2 == lc || cpg * 4 == lc;        // groups are whole inside a lane's 4*NT columns
     if (!d->R1 && !d->R2 && !d->a1 && !d->a2) {
       if (whole) { p.gn_part = d->gn_partial; g_gn_fused = 1; }
-    } else if (whole && !env.gn_post_off && p.vec8 && ((!d->a1 && !d->a2) || d->rows_per_group % 256 == 0)) {
+    } else if (whole && !env.gn_post_off && p.vec8 && ((!d->a1 && !d->a2) || d->rows_per_group % bm == 0)) {
       // residual / blend terms after the accumulators (round 6): they are added in the accumulator layout before the store loop
       // (GemmParams.gn_post), the statistics taken from the final values.  Full tiles, bf16 out, 16-byte rows, one row group per
       // tile: every wave tile takes the kernel's interior store path

@@ -18,8 +18,13 @@ def test_no_hot_kernel_spills_to_scratch():
     assert len(res) > 40
     gemm = {k: v for k, v in res.items() if "gemm_bf16_kernel" in k}
     assert gemm and any("ffn_geglu" in k for k in res) and any("attn_d64" in k for k in res)
-    spilled = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0)}
+    # one bounded, measured exception (round 6, build._spill_tolerated): the single-stage 128 x 128 tile is held to 128 registers for
+    # FOUR blocks per CU and parks <= 32 B per lane outside its K loop
+    spilled = {k: v["scratch"] for k, v in res.items()
+               if v.get("scratch", 0) and not ("gemm_bf16_kernelILi2ELi4ELi1E" in k and v["scratch"] <= 32)}
     assert not spilled, spilled
+    four = [v for k, v in gemm.items() if "ILi2ELi4ELi1E" in k]
+    assert four and all(v["vgprs"] <= 128 and v["occupancy"] >= 4 for v in four), four
     # the instantiations the stage-2 step actually dispatches keep two blocks per CU (occupancy 2 with 256 threads)
     for k, v in gemm.items():
         if "ILi2ELi5ELi2E" in k:

@@ -146,6 +146,78 @@ def test_gemm_tile_variants(dev, variant, monkeypatch):
     assert relerr(outc, refc) < BF16_TOL
 
 
+@pytest.mark.parametrize("N", [128, 384, 200, 72, 100])
+def test_gemm_single_stage_128_tile_runs_the_per_wave_epilogue(dev, N, monkeypatch):
+    """Round 6: the single-stage 128 x 128 tile (variant 3 where the 128-column tile is chosen: four blocks per CU, the VAE's
+    128-channel convs) runs the wide tiles' per-wave epilogue.  Forced onto ragged shapes: M and N tails (N = 200 / 72: a partial
+    last column tile; N = 100: rows that are not 16-byte multiples), row groups that do not align with the tile, every epilogue
+    term, fp32 output, GEGLU, the conv3x3 gathers (stride 1 / 2 / 2x up-sampling) and Conv3d (3,1,1) -- against fp32 torch, and
+    bit-identical to the two-stage tile (variant 0, block-wide epilogue: same operations in the same order)."""
+    from hi3d_hip import ops
+    from hi3d_hip.pack import pack_conv3x3, pack_convt3, pack_geglu
+    M, K, rpg = 700, 192, 96
+    G = (M + rpg - 1) // rpg
+    A, W = bf(rnd((M, K), 11)), bf(rnd((N, K), 12, K ** -0.5))
+    bias, rowvec = rnd((N,), 13), rnd((G, N), 14)
+    R1, R2 = bf(rnd((M, N), 15)), bf(rnd((M, N), 16))
+    a1, a2 = rnd((G,), 17).abs() + 0.5, rnd((G,), 18)
+    grp = torch.arange(M) // rpg
+    ref = (A.float() @ W.float().T + bias + rowvec[grp] + R1.float()) * a1[grp, None] + a2[grp, None] * R2.float()
+    Fr, H, Wd, Cin = 3, 12, 10, 64
+    x = bf(rnd((Fr, Cin, H, Wd), 21))
+    wc, bc = bf(rnd((N, Cin, 3, 3), 22, (9 * Cin) ** -0.5)).float(), rnd((N,), 23)
+    xt = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Cin)
+    Rc = bf(rnd((Fr * H * Wd, N), 24))
+    T, HW = 3, 80
+    xv = bf(rnd((2, N, T, HW, 1), 25)) if N % 64 == 0 else None
+    wt = bf(rnd((N, N, 3, 1, 1), 26, (3 * N) ** -0.5)).float() if N % 64 == 0 else None
+
+    def run():
+        o = {}
+        o["affine"] = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K, bias=bias.to(dev), rowvec=rowvec.to(dev), ldrv=N, rows_per_group=rpg,
+                               R1=R1.to(dev), R2=R2.to(dev), a1=a1.to(dev), a2=a2.to(dev))
+        o["fp32"] = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K, bias=bias.to(dev), R1=R1.to(dev), out_fp32=True)
+        o["plain"] = ops.gemm(A.to(dev), W.to(dev), M=M, N=N, K=K)
+        for name, st, up in (("conv", 1, 0), ("conv_s2", 2, 0), ("conv_up", 1, 1)):
+            Ho, Wo = (H * 2, Wd * 2) if up else (H // st, Wd // st)
+            kw = dict(R1=Rc.to(dev)) if name == "conv" else {}
+            o[name] = ops.gemm(xt.to(dev), pack_conv3x3(wc, Cin).to(dev), M=Fr * Ho * Wo, N=N, K=9 * Cin, bias=bc.to(dev),
+                               conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=st, up2x=up), **kw)
+        if xv is not None:
+            xvt = xv.squeeze(-1).permute(0, 2, 3, 1).contiguous().reshape(-1, N)
+            o["convt"] = ops.gemm(xvt.to(dev), pack_convt3(wt).to(dev), M=2 * T * HW, N=N, K=3 * N, convt3=dict(T=T, HW=HW, Cin=N))
+        if N % 16 == 0:
+            Wg, bg = bf(rnd((2 * N, K), 19, K ** -0.5)).float(), rnd((2 * N,), 20)
+            Wp, bp = pack_geglu(Wg, bg)
+            o["geglu"] = ops.gemm(A.to(dev), Wp.to(dev), M=M, N=2 * N, K=K, bias=bp.to(dev), geglu=True, tile_n=128)
+            o["geglu_ref"] = (Wg, bg)
+        return o
+
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", "3")
+    got = run()
+    monkeypatch.setenv("HI3D_GEMM_VARIANT", "0")
+    base = run()
+    assert relerr(got["affine"], ref) < BF16_TOL
+    assert relerr(got["fp32"], A.float() @ W.float().T + bias + R1.float()) < 2e-3 and got["fp32"].dtype == torch.float32
+    assert relerr(got["plain"], A.float() @ W.float().T) < BF16_TOL
+    refc = F.conv2d(x.float(), wc, bc, padding=1).permute(0, 2, 3, 1).reshape(-1, N) + Rc.float()
+    assert relerr(got["conv"], refc) < BF16_TOL
+    refs2 = F.conv2d(x.float(), wc, bc, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    assert relerr(got["conv_s2"], refs2) < BF16_TOL
+    refup = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), wc, bc, padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    assert relerr(got["conv_up"], refup) < BF16_TOL
+    if xv is not None:
+        reft = F.conv3d(xv.float(), wt, None, padding=(1, 0, 0))
+        assert relerr(got["convt"].float().cpu().reshape(2, T, HW, N).permute(0, 3, 1, 2).unsqueeze(-1), reft) < BF16_TOL
+    if "geglu" in got:
+        Wg, bg = got["geglu_ref"]
+        h = A.float() @ Wg.T + bg
+        assert relerr(got["geglu"], h[:, :N] * F.gelu(h[:, N:])) < BF16_TOL
+    for k in got:
+        if k != "geglu_ref":
+            assert torch.equal(got[k], base[k]), f"{k}: the per-wave epilogue of the single-stage tile differs from the block-wide one"
+
+
 @pytest.mark.parametrize("variant", [6, 7, 8])
 def test_gemm_pingpong_long_k_race_screen(dev, variant, monkeypatch):
     """The ping-pong K loops (staggered wave halves, counted vmcnt, LDS ring re-used every 2-3 K steps) on a
@@ -621,7 +693,8 @@ def test_groupnorm_single_pass_small_slabs(dev, inst, P, C, C1, silu):
     assert torch.equal(out, again)                                           # fixed summation order
 
 
-@pytest.mark.parametrize("variant,N,three_d", [(7, 320, False), (7, 640, True), (7, 1280, False), (8, 256, False), (8, 512, True)])
+@pytest.mark.parametrize("variant,N,three_d", [(7, 320, False), (7, 640, True), (7, 1280, False), (8, 256, False), (8, 512, True),
+                                               (3, 128, False), (3, 256, True), (3, 512, False)])   # 3: the single-stage 128 x 128 tile (round 6)
 def test_groupnorm_statistics_from_the_producing_conv(dev, variant, N, three_d, monkeypatch):
     """Round 4: a conv whose output feeds a GroupNorm (ResBlock in_layers.2 -> out_layers.0, openaimodel.py:292-305; the
     time_stack likewise) emits that norm's partial sums from its accumulators (hi3d_gemm_desc.gn_partial, wide ping-pong tile),
@@ -657,7 +730,8 @@ def test_groupnorm_statistics_from_the_producing_conv(dev, variant, N, three_d, 
 
 
 @pytest.mark.parametrize("variant,N,kind", [(7, 320, "conv_R1"), (7, 640, "conv_R1"), (7, 1280, "dense_R1"), (7, 320, "convt_blend"),
-                                            (7, 640, "convt_blend"), (7, 320, "dense_R1"), (8, 256, "conv_R1"), (8, 512, "dense_R1")])
+                                            (7, 640, "convt_blend"), (7, 320, "dense_R1"), (8, 256, "conv_R1"), (8, 512, "dense_R1"),
+                                            (3, 128, "conv_R1"), (3, 512, "dense_R1"), (3, 256, "convt_blend")])
 def test_groupnorm_statistics_from_residual_and_blend_epilogues(dev, variant, N, kind, monkeypatch):
     """Round 6: the producers whose epilogue ADDS something after the accumulators -- out_layers.3 + skip
     (openaimodel.py:353-354), the time_stack blend x_s + (1 - alpha) h_t (video_model.py:77-79), proj_out + x_in

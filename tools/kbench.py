@@ -327,7 +327,8 @@ def bench_vae_sweep():
     re-read through hi3d_gemm_reload_env); 'h' = the host heuristic."""
     variants = sys.argv[2:] or ["h", "0", "1", "2", "3", "6", "8"]
     shapes = ((1, 1024, 128, 128, True), (1, 1024, 128, 128, False), (1, 1024, 256, 128, False), (1, 512, 256, 256, True),
-              (1, 512, 512, 256, False), (1, 256, 512, 512, True), (4, 1024, 128, 128, True))
+              (1, 512, 512, 256, False), (1, 256, 512, 512, True), (4, 1024, 128, 128, True), (1, 128, 512, 512, True),
+              (1, 128, 512, 512, False), (16, 512, 128, 128, True))
     for Fr, H, Cin, Cout, res in shapes:
         M, K = Fr * H * H, 9 * Cin
         A, W = rb(M, Cin), rb(Cout, K)
