@@ -1264,7 +1264,7 @@ extern "C" int hi3d_gemm_bf16(const hi3d_gemm_desc* d, void* stream) {
     if (ph < 0 || ph > 3) HI3D_FAIL(HI3D_EINVAL, "conv3x3: conv_phase must be 0 or 1..4");
     const bool ok = d->amode == HI3D_A_CONV3X3 && d->conv_ntap > 0 && !d->up2x && d->stride == 1 && d->Hout == d->Hin &&
                     d->Wout == d->Win && d->Win % 16 == 0 && d->M % 256 == 0 && d->N % tile == 0 && (variant == 7 || variant == 8) &&
-                    ksplit == 1 && !d->R1 && !d->R2 && !d->rowvec && !d->a1 && !d->a2 && !d->out_fp32 && p.vec8 && !d->gn_partial &&
+                    ksplit == 1 && !d->R1 && !d->R2 && !d->rowvec && !d->a1 && !d->a2 && !d->out_fp32 && p.vec8 &&
                     4L * d->M * d->ldo * 2 < (1L << 31);
     if (!ok) HI3D_FAIL(HI3D_ESHAPE, "conv3x3: phase-placed output needs a tap subset, a wide tile (full tiles, >= 256 of them), Win % 16 == 0, "
                                      "a bias-only bf16 epilogue and a 2x image below 2 GiB");

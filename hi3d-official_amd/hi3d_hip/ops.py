@@ -148,7 +148,7 @@ def _ensure_gemm_workspace(dev, stream=None):
 
 def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_group=1,
          R1=None, R2=None, a1=None, a2=None, out_fp32=False, geglu=False,
-         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, gn=None, w_group_stride=0):
+         lda=None, ldw=0, conv3x3=None, convt3=None, tile_n=0, A2=None, K1=0, lda2=None, gn=None, w_group_stride=0, gn_at=None):
     """out[M, N(/2 if geglu)] = epilogue(A (*) W^T).  See include/hi3d_hip.h.
 
     conv3x3 = dict(Hin, Win, Cin, Hout, Wout, stride, up2x); convt3 = dict(T, HW, Cin).
@@ -156,7 +156,10 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     gn = (inst, P): the output is the input of a GroupNorm(32) over `inst` instances of P rows -- ask the producer to emit the
     norm's partial sums from its accumulators (hi3d_gemm_desc.gn_partial).  Returns (out, ws): ws is the GroupNorm workspace
     holding them (pass it to groupnorm_silu(..., partials=ws): the statistics pass is skipped), or None when this launch
-    cannot provide them (the caller then runs the plain groupnorm_silu)."""
+    cannot provide them (the caller then runs the plain groupnorm_silu).
+    gn_at = (ws, first): like gn, with the caller's workspace -- this launch's M / 64 row blocks of partial sums go to block
+    `first` onwards (float offset 64 * first) of ws: launches that each produce PART of a tensor's rows (the four phase launches
+    of an up-sampling conv).  Returns (out, ws or None)."""
     d, out = gemm_desc(A, W, M=M, N=N, K=K, out=out, bias=bias, rowvec=rowvec, ldrv=ldrv, rows_per_group=rows_per_group, R1=R1, R2=R2,
                        a1=a1, a2=a2, out_fp32=out_fp32, geglu=geglu, lda=lda, ldw=ldw, conv3x3=conv3x3, convt3=convt3, tile_n=tile_n,
                        A2=A2, K1=K1, lda2=lda2, w_group_stride=w_group_stride)
@@ -166,6 +169,9 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
     if gn is not None and GN_FUSED and gn[1] % 64 == 0 and gn[0] * gn[1] == M:
         gn_ws = _gn_workspace(A.device, gn[0], gn[1], n_out)
         d.gn_partial = _p(gn_ws)
+    elif gn_at is not None and GN_FUSED and M % 64 == 0:
+        gn_ws = gn_at[0]
+        d.gn_partial = gn_ws.data_ptr() + 4 * 64 * int(gn_at[1])
     prof = PROFILER
     t0 = prof.begin() if prof else None
     _l.check(_lib.hi3d_gemm_bf16(d, _stream()), "hi3d_gemm_bf16")
@@ -188,7 +194,7 @@ def gemm(A, W, *, M, N, K, out=None, bias=None, rowvec=None, ldrv=0, rows_per_gr
         osz = 2.0 if out_fp32 else 1.0
         prof.end(fam, 2.0 * M * N * K, 2.0 * (a_elems + N * K + M * n_out * (osz + nres)), t0,
                  detail=f"M={M} N={N} K={K}{geo} {epi}")
-    return out if gn is None else (out, gn_ws)
+    return out if (gn is None and gn_at is None) else (out, gn_ws)
 
 
 def gemm_reload_env():
@@ -454,12 +460,16 @@ UP_PHASE_PLACED = os.environ.get("HI3D_UP_PHASE_PLACED", "1") != "0"
 _PHASE_PLACED_OK = {}
 
 
-def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C, placed=None):
+def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C, placed=None, gn=False):
     """Upsample(nearest 2x) + conv3x3 pad 1 on x [frames * H * Wd, C] (channels-last rows) -> [frames * 2H * 2Wd, C] as four 2x2
     phase convolutions on the low-resolution image (pack.pack_conv3x3_up_phases: w_phases[a * 2 + b] = [C, 4 * C]): the phases are
     written planar [a][b][(f i)][j] and interleaved to [(f i)][a][j][b] by hi3d_permute_rows -- or, `placed` (default:
     HI3D_UP_PHASE_PLACED) and where the launch qualifies (wide tile, Wd % 16 == 0), every phase stores its rows straight into the 2x
-    image (hi3d_gemm_desc.conv_phase)."""
+    image (hi3d_gemm_desc.conv_phase).
+    gn=True: returns (out, ws) -- ws the GroupNorm workspace with the partial sums of `out` as ONE instance of 4 * frames * H * Wd
+    rows (a one-frame VAE call: pass it to groupnorm_silu(..., 1, rows, C, partials=ws)), each placed phase launch filling its quarter
+    of the row blocks (the order of the blocks inside an instance does not matter to the sums) -- or None when frames != 1 or a
+    launch cannot provide them."""
     Ml = frames * H * Wd
     placed = UP_PHASE_PLACED if placed is None else placed
     geo = lambda ph: dict(Hin=H, Win=Wd, Cin=C, Hout=H, Wout=Wd, stride=1, up2x=0,
@@ -467,10 +477,15 @@ def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C, placed=None):
     key = (x.device.index, Ml, H, Wd, C)
     if placed and _PHASE_PLACED_OK.get(key, True):
         out = torch.empty((4 * Ml, C), device=x.device, dtype=torch.bfloat16)
+        ws = _gn_workspace(x.device, 1, 4 * Ml, C) if (gn and frames == 1 and Ml % 64 == 0 and GN_FUSED) else None
         try:
             for ph in range(4):
-                gemm(x, w_phases[ph], M=Ml, N=C, K=4 * C, bias=bias, out=out, conv3x3=dict(geo(ph), phase=(ph >> 1, ph & 1)))
-            return out
+                kw = dict(M=Ml, N=C, K=4 * C, bias=bias, out=out, conv3x3=dict(geo(ph), phase=(ph >> 1, ph & 1)))
+                if ws is None:
+                    gemm(x, w_phases[ph], **kw)
+                elif gemm(x, w_phases[ph], gn_at=(ws, ph * (Ml // 64)), **kw)[1] is None:
+                    ws = None
+            return (out, ws) if gn else out
         except _l.Hi3dError:
             if ph != 0:                              # (the shape check is the same for the four phases: it fails at the first or never)
                 raise
@@ -478,7 +493,8 @@ def upsample_conv_phases(x, w_phases, bias, frames, H, Wd, C, placed=None):
     tmp = torch.empty((4, Ml, C), device=x.device, dtype=torch.bfloat16)
     for ph in range(4):
         gemm(x, w_phases[ph], M=Ml, N=C, K=4 * C, bias=bias, out=tmp[ph], conv3x3=geo(ph))
-    return permute_rows(tmp, (2, 2, frames * H, Wd), (2, 0, 3, 1)).reshape(4 * Ml, C)
+    out = permute_rows(tmp, (2, 2, frames * H, Wd), (2, 0, 3, 1)).reshape(4 * Ml, C)
+    return (out, None) if gn else out
 
 
 def layernorm(x, gamma, beta, R, C, eps=1e-5, addvec=None, rows_per_group=1, sum_out=None, out=None):

@@ -149,10 +149,12 @@ class VAEDecoderRuntime:
 
     # ------------------------------------------------------------------
     def _conv(self, x, key, N, H, Wd, Cin, Cout, up=0, R1=None, out_fp32=False, gn=None):
-        if up and UP_PHASES and (key + ".w.ph0") in self.W and R1 is None and not out_fp32 and gn is None and Cin == Cout:
+        if up and UP_PHASES and (key + ".w.ph0") in self.W and R1 is None and not out_fp32 and Cin == Cout:
             # Upsample (nearest 2x) + conv3x3 (model.py:67-71) as four 2x2 convolutions on the low-resolution image, one per
             # output phase, with summed weights (pack.pack_conv3x3_up_phases): 4/9 of the multiply-adds, then one row interleave
-            return ops.upsample_conv_phases(x, [self.W[f"{key}.w.ph{ph}"] for ph in range(4)], self.W[key + ".b"], N, H, Wd, Cout)
+            # (gn: the next norm's partial sums from the four placed launches -- one-frame calls)
+            return ops.upsample_conv_phases(x, [self.W[f"{key}.w.ph{ph}"] for ph in range(4)], self.W[key + ".b"], N, H, Wd, Cout,
+                                            gn=gn is not None)
         Ho, Wo = (2 * H, 2 * Wd) if up else (H, Wd)
         return ops.gemm(x, self.W[key + ".w"], M=N * Ho * Wo, N=Cout, K=9 * Cin, bias=self.W[key + ".b"], R1=R1,
                         out_fp32=out_fp32, conv3x3=dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=1, up2x=up), gn=gn)
@@ -220,7 +222,8 @@ class VAEDecoderRuntime:
                 h = self._resnet(f"up.{lvl}.block.{b}", h, N, H, Wd, cin, cout)
                 cin = cout
             if lvl != 0:
-                h = self._conv(h, f"up.{lvl}.up", N, H, Wd, cout, cout, up=1)
+                h, gpu_ = self._conv(h, f"up.{lvl}.up", N, H, Wd, cout, cout, up=1, gn=(N, 4 * H * Wd))
+                self._gp = None if gpu_ is None else (h, gpu_)      # (the next level's first norm1)
                 H, Wd = 2 * H, 2 * Wd
         h = ops.groupnorm_silu(h, W["norm_out.g"], W["norm_out.b"], N, H * Wd, cin, 1e-6, partials=self._take_gp(h))
         ocp = W["conv_out.b"].numel()

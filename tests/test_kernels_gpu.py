@@ -432,6 +432,17 @@ def test_upsample_phase_convs_placed_in_the_2x_image(dev, Fr, H, W_, C):
         assert not bool(bad.any()), f"rep {rep}: {int(bad.sum())} of {4 * Ml} rows differ from the planar + interleave form " \
                                     f"(first: {bad.nonzero()[:8].flatten().tolist()}, NaN rows: {int(torch.isnan(out.float()).any(dim=1).sum())})"
     assert torch.equal(ops.upsample_conv_phases(xt, wp, b, Fr, H, W_, C, placed=True), planar)
+    # the GroupNorm that reads the 2x image (the VAE's next norm1): its partial sums from the four placed launches, each filling
+    # its quarter of the row blocks -- one-frame calls only (the blocks of an instance must be contiguous)
+    out_g, ws = ops.upsample_conv_phases(xt, wp, b, Fr, H, W_, C, placed=True, gn=True)
+    assert torch.equal(out_g, planar)
+    assert (ws is not None) == (Fr == 1)
+    if ws is not None:
+        gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        fused = ops.groupnorm_silu(out_g, gam, bet, 1, 4 * Ml, C, 1e-6, partials=ws)
+        three = ops.groupnorm_silu(out_g, gam, bet, 1, 4 * Ml, C, 1e-6)
+        ref = F.silu(F.group_norm(out_g.float().reshape(1, 4 * Ml, C).permute(0, 2, 1), 32, gam, bet, 1e-6)).permute(0, 2, 1).reshape(4 * Ml, C)
+        assert relerr(fused.float().cpu(), ref.cpu()) < BF16_TOL and relerr(fused.float().cpu(), three.float().cpu()) < 8e-3
     with pytest.raises(ops._l.Hi3dError):               # Win % 16 != 0: not a placed launch (the wrapper falls back to planar)
         ops.gemm(xt[:Fr * H * 24], wp[0], M=Fr * H * 24, N=C, K=4 * C, bias=b, out=torch.empty((4 * Fr * H * 24, C), device=dev, dtype=torch.bfloat16),
                  conv3x3=dict(Hin=H, Win=24, Cin=C, Hout=H, Wout=24, stride=1, up2x=0, taps=(0, 1, 3, 4), phase=(0, 0)))
