@@ -126,8 +126,9 @@ typedef struct hi3d_gemm_desc {
   const void* A2;
   int32_t K1, lda2;
   /* GroupNorm statistics of the OUTPUT from the producer (round 4; NULL = off): when the launch qualifies
-   * (hi3d_gemm_gn_partial_supported: wide tile, M % 256 == 0, N a whole number of tiles, bf16 out; round 6: R1 / R2 / a1 / a2 are
-   * allowed -- 16-byte residual rows, one row group per 256-row tile --, the sums are then those of the FINAL values) the
+   * (hi3d_gemm_gn_partial_supported: a wide tile -- or, round 6, the single-stage 128 x 128 tile the VAE's 128- / 256- / 512-channel
+   * convs run on --, M a whole number of tile rows (256 / 128), N a whole number of tiles, bf16 out; round 6: R1 / R2 / a1 / a2 are
+   * allowed -- 16-byte residual rows, one row group per tile --, the sums are then those of the FINAL values) the
    * kernel also writes, per 64-row block b of the output and per group g of N / 32 channels, the (sum, sum of squares) of the
    * fp32 results to gn_partial[b * 64 + 2 g + {0, 1}] -- M / 64 * 64 floats, the partial-sum layout of hi3d_groupnorm_silu's
    * workspace with 64-pixel blocks -- so the GroupNorm that follows (openaimodel.py:292-294 `out_layers` after the
@@ -151,7 +152,9 @@ typedef struct hi3d_gemm_desc {
    * image [frames * 2 Hin * 2 Win, ldo]: row (f, i, j) of this launch is stored as pixel (f, 2 i + a, 2 j + b) -- no planar phase
    * images, no interleave pass (openaimodel.py:107-146 Upsample; model.py:67-71).  Needs a tap subset, the wide tiles (full tiles,
    * >= 256 of them), Win % 16 == 0, a bias-only bf16 epilogue, the 2x image below 2 GiB; HI3D_ESHAPE otherwise (the caller
-   * falls back to planar phase images + hi3d_permute_rows). */
+   * falls back to planar phase images + hi3d_permute_rows).  gn_partial may be set: the launch then fills the M / 64 row blocks of
+   * ITS rows (source-row order) at the pointer given -- four phase launches with pointers M floats apart cover the 2x image's
+   * 4 M / 64 blocks, which describe ONE GroupNorm instance in any order (a one-frame call: model.py:715-748, the next norm1). */
   int32_t conv_phase;
 } hi3d_gemm_desc;
 
