@@ -105,7 +105,7 @@ def bench_norm(F=32, lat=128):
         print(f"  R={R:7d} C={C:5d}: {ms:8.3f} ms  {2.0 * 2 * R * C / ms / 1e6:8.1f} GB/s")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1", "tattn", "vaesweep")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("one", "attn1", "ffn", "sweep", "conv1", "tattn", "vaesweep", "upphase")):
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lat = 64 if "--s1" in sys.argv else 128
     if which in ("gemm", "all"):
@@ -362,3 +362,43 @@ def bench_vae_sweep():
 
 if len(sys.argv) > 1 and sys.argv[1] == "vaesweep":
     bench_vae_sweep()
+
+
+def bench_up_phases():
+    """kbench.py upphase [variants...] : the VAE decoder's up-sampling convs (one frame) as four placed phase launches under each
+    tile variant; checks every variant against the planar + interleave form of the same tile.  CAUTION (round 6): one pass in a
+    fixed order -- the first variant of a shape runs on cooler clocks and reads 5-10 % slower than the same tile measured last
+    (profiles/r06w_up_phase_variants*.log: `h` = variant 3 there, 0.657 vs 0.582 ms); decide with an alternated A/B
+    (tools/ab_lib_vae.sh), which is what refuted this sweep's apparent 11 % for the four-block tile on the phase launches."""
+    from hi3d_hip.pack import pack_conv3x3_up_phases
+    variants = sys.argv[2:] or ["h", "8", "3"]
+    for Fr, H, C in ((1, 512, 256), (1, 256, 512), (1, 128, 512), (16, 256, 256), (16, 64, 640)):
+        x = rb(Fr * H * H, C)
+        w = (torch.randn((C, C, 3, 3)) * (9 * C) ** -0.5).to(torch.bfloat16).float()
+        b = torch.randn(C, device=dev)
+        wp = [p_.to(dev) for p_, _ in pack_conv3x3_up_phases(w)]
+        line = f"up-conv F={Fr} {H}->{2 * H} C={C}:"
+        fl = 2.0 * 4 * Fr * H * H * C * 4 * C
+        for v in variants:
+            if v == "h":
+                os.environ.pop("HI3D_GEMM_VARIANT", None)
+            else:
+                os.environ["HI3D_GEMM_VARIANT"] = v
+            ops.gemm_reload_env()
+            ops._PHASE_PLACED_OK.clear()
+            try:
+                out = ops.upsample_conv_phases(x, wp, b, Fr, H, H, C, placed=True)
+                placed_ok = ops._PHASE_PLACED_OK.get((x.device.index, Fr * H * H, H, H, C), True)
+                ms = timeit(lambda: ops.upsample_conv_phases(x, wp, b, Fr, H, H, C, placed=True), iters=5, warm=2)
+                ref = ops.upsample_conv_phases(x, wp, b, Fr, H, H, C, placed=False)
+                line += f"  {v}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF ({'placed' if placed_ok else 'planar fallback'}{'' if torch.equal(out, ref) else ', DIFFERS from its planar form'})"
+            except Exception as e:      # noqa: BLE001
+                line += f"  {v}: n/a ({str(e)[:40]})"
+        print(line, flush=True)
+    os.environ.pop("HI3D_GEMM_VARIANT", None)
+    ops.gemm_reload_env()
+    ops._PHASE_PLACED_OK.clear()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "upphase":
+    bench_up_phases()
